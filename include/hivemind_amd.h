@@ -1,0 +1,146 @@
+/*
+ * hivemind_amd.h — C ABI of the MI355X-native Bughouse rollout engine.
+ *
+ * This is the drop-in boundary for the self-play hot path of aminwoo/hivemind.
+ * Every entry point names the reference interface it replaces (file:line is
+ * relative to the reference tree's engine/src/).  Plain pointers and sizes
+ * only; device pointers are HIP device memory (e.g. torch.Tensor.data_ptr()).
+ * All functions return 0 on success and a negative hm_status on failure;
+ * hm_last_error() gives the message.  Nothing here falls back to a CPU path:
+ * a call that needs the GPU fails with HM_ERR_NO_DEVICE when there is none.
+ */
+#ifndef HIVEMIND_AMD_H
+#define HIVEMIND_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (environment/constants.h:10-22) ---- */
+#define HM_NB_PLANES            74      /* NB_INPUT_CHANNELS */
+#define HM_NB_PLANES_PER_BOARD  37
+#define HM_PLANE_VALUES         4736    /* NB_INPUT_VALUES() = 74*8*8 */
+#define HM_POLICY_VALUES        4672    /* NB_POLICY_VALUES() = 73*8*8 */
+#define HM_MAX_MOVES            512     /* per-board legal move cap of the batched movegen
+                                           (reference MAX_MOVES=1024, types.h:226; bound: 48 P-drops + 4*62 drops + 8 king = 304) */
+
+/* Move encoding is Fairy-Stockfish's 32-bit Move (types.h:237-263,735-799):
+ * bits 0-5 to, 6-11 from, 12-15 type, 16-21 promotion / dropped piece type,
+ * 22-27 in-hand piece type.  0 == MOVE_NONE == pass/sit (board.h:340-343). */
+typedef uint32_t hm_move;
+#define HM_MOVE_NONE       0u
+#define HM_MT_NORMAL       (0u << 12)
+#define HM_MT_EN_PASSANT   (1u << 12)
+#define HM_MT_CASTLING     (2u << 12)   /* king-from -> rook-square */
+#define HM_MT_PROMOTION    (3u << 12)
+#define HM_MT_DROP         (4u << 12)
+
+enum { HM_WHITE = 0, HM_BLACK = 1 };
+enum { HM_PAWN = 1, HM_KNIGHT = 2, HM_BISHOP = 3, HM_ROOK = 4, HM_QUEEN = 5, HM_KING = 6 };
+/* castling bits == Stockfish::CastlingRights (types.h:262-277) */
+enum { HM_WHITE_OO = 1, HM_WHITE_OOO = 2, HM_BLACK_OO = 4, HM_BLACK_OOO = 8 };
+
+typedef enum hm_status {
+    HM_OK = 0,
+    HM_ERR_INVALID = -1,      /* bad argument */
+    HM_ERR_NO_DEVICE = -2,    /* no HIP device / kernel launch failed */
+    HM_ERR_ILLEGAL = -3,      /* illegal joint action (board.cc:317-322 throws logic_error) */
+    HM_ERR_OVERFLOW = -4,     /* a caller-owned buffer or pool is too small */
+    HM_ERR_STATE = -5         /* call made in the wrong state (e.g. second enqueue before sync) */
+} hm_status;
+
+/* One board.  Replaces Stockfish::Position + StateInfo (position.h:40-85,338-358)
+ * for the bughouse variant: 96 bytes, no pointers, trivially copyable (copy-make
+ * instead of do/undo).  `key` is bit-identical to StateInfo::key. */
+typedef struct hm_pos {
+    uint64_t by_type[6];    /* P,N,B,R,Q,K bitboards, both colours; a1 = bit 0 */
+    uint64_t by_color[2];   /* white, black */
+    uint64_t promoted;      /* Position::promotedPieces */
+    uint64_t key;           /* Zobrist key incl. side, castling, ep file, in-hand counts */
+    uint8_t  hand[2][5];    /* pieceCountInHand[colour][P,N,B,R,Q] */
+    uint8_t  castling;      /* CastlingRights bits */
+    uint8_t  ep;            /* en-passant square or 64 = none */
+    uint8_t  stm;           /* side to move */
+    uint8_t  rule50;        /* halfmove clock */
+    uint16_t game_ply;
+} hm_pos;
+
+/* Two boards + the history-derived scalars the plane encoder needs.
+ * Replaces `Board` (environment/board.h:25-454) as the encoder's input. 208 bytes. */
+typedef struct hm_board {
+    hm_pos   pos[2];        /* BOARD_A, BOARD_B */
+    uint32_t last_move[2];  /* Board::last_move(b) (board.h:319-324); 0 = none */
+    uint8_t  rep_count[2];  /* Board::repetition_count(b) (board.h:326-332), saturated at 3 */
+    uint8_t  team;          /* teamSide the planes are oriented for */
+    uint8_t  time_adv;      /* hasTimeAdvantage */
+    uint32_t reserved;
+} hm_board;
+
+/* plane output element types */
+enum { HM_DT_F16 = 0, HM_DT_F32 = 1, HM_DT_U8 = 2 };
+
+/* ------------------------------------------------------------------ */
+/* library                                                              */
+/* ------------------------------------------------------------------ */
+
+/* Builds attack/Zobrist/policy tables on the host and uploads them to the
+ * current HIP device.  Replaces the start-up sequence of main.cc:75-81
+ * (Bitboards::init, Position::init, init_policy_index).  Idempotent. */
+int hm_init(int device);
+/* Message of the last failure on this thread (never NULL). */
+const char* hm_last_error(void);
+/* 1 when a HIP device is usable by this library build, else 0. */
+int hm_device_available(void);
+/* Library ABI version. */
+int hm_abi_version(void);
+
+/* ------------------------------------------------------------------ */
+/* positions                                                            */
+/* ------------------------------------------------------------------ */
+
+/* Fills `out` with the dual start position (Board::Board(), board.cc:52-69). */
+int hm_board_startpos(hm_board* out);
+
+/* Host-side helper: policy index of a move for the side to move
+ * (get_fast_policy_index, common/utils.h:184-216). -1 = unrepresentable. */
+int hm_policy_index(hm_move m, int stm);
+
+/* ------------------------------------------------------------------ */
+/* batched plane encoder: board_to_planes (environment/planes.h:20-22,  */
+/* planes.cc:213-265), one launch for n positions.                      */
+/* d_boards: device, n * sizeof(hm_board).  d_out: device,              */
+/* n * 4736 elements of `dtype` (U8 = round(v*255), selfplay.cc:464-476).*/
+/* stream: hipStream_t as void* (NULL = default stream).                */
+/* ------------------------------------------------------------------ */
+int hm_encode_planes(const hm_board* d_boards, size_t n, int dtype, void* d_out, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* batched legal move generation: Board::legal_moves(board_num)         */
+/* (board.cc:133-139 -> generate<LEGAL>, movegen.cpp:439-456), in the   */
+/* reference's list order.  d_pos: n positions; d_moves: n*HM_MAX_MOVES;*/
+/* d_counts: n.                                                         */
+/* ------------------------------------------------------------------ */
+int hm_legal_moves(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_counts, void* stream);
+
+/* Batched joint make: Board::make_moves (board.cc:316-341) applied to
+ * d_boards[i] with (d_move_a[i], d_move_b[i]); writes d_out[i]; no legality
+ * re-check (the caller passes moves produced by hm_legal_moves). */
+int hm_make_moves(const hm_board* d_boards, const hm_move* d_move_a, const hm_move* d_move_b,
+                  size_t n, hm_board* d_out, void* stream);
+
+/* ------------------------------------------------------------------ */
+/* joint perft: benchmark_movegen / perft (tools/benchmark.cc:59-97).   */
+/* Counts with the reference's convention (depth 1 = |A|*|B|) from      */
+/* `root` (host pointer).  Runs entirely on the device.                 */
+/* shard/nshards split the depth-2 frontier across ranks (weak scaling  */
+/* by game/stripe: no collective).  *nodes = this shard's count.        */
+/* ------------------------------------------------------------------ */
+int hm_perft(const hm_board* root, int depth, int shard, int nshards, uint64_t* nodes, double* seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIVEMIND_AMD_H */
