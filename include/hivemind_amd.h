@@ -125,6 +125,10 @@ int hm_encode_planes(const hm_board* d_boards, size_t n, int dtype, void* d_out,
 /* ------------------------------------------------------------------ */
 int hm_legal_moves(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_counts, void* stream);
 
+/* Legal move COUNT only (MoveList<LEGAL>::size(), used by is_checkmate board.cc:169-208 and
+ * the perft depth-1 shortcut benchmark.cc:66). d_counts: n. */
+int hm_count_moves(const hm_pos* d_pos, size_t n, uint32_t* d_counts, void* stream);
+
 /* Batched joint make: Board::make_moves (board.cc:316-341) applied to
  * d_boards[i] with (d_move_a[i], d_move_b[i]); writes d_out[i]; no legality
  * re-check (the caller passes moves produced by hm_legal_moves). */

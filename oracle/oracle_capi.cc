@@ -1,0 +1,151 @@
+// oracle/oracle_capi.cc — C entry points of the CPU oracle for ctypes (tests, smoke,
+// bench cpu_baseline).  TEST INFRASTRUCTURE ONLY: nothing under hivemind_amd/ links this.
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "bughouse.hpp"
+#if __has_include("search.hpp")
+#include "search.hpp"
+#endif
+
+using namespace hmo;
+
+static std::string uci_of(const Pos& p, Move m) {   // Fairy-Stockfish stubs.cpp:20-58
+    if (m == MOVE_NONE) return "pass";              // Board::uci_move (board.h:340-343)
+    auto sq = [](int s) { std::string r; r += char('a' + (s & 7)); r += char('1' + (s >> 3)); return r; };
+    int from = from_sq(m), to = to_sq(m);
+    if (type_of(m) == CASTLING) to = (from & 56) + (to > from ? 6 : 2);
+    std::string s;
+    if (type_of(m) == DROP) { s += " PNBRQK"[promo_type(m)]; s += '@'; }
+    else s += sq(from);
+    s += sq(to);
+    if (type_of(m) == PROMOTION) s += " pnbrqk"[promo_type(m)];
+    (void)p;
+    return s;
+}
+
+extern "C" {
+
+void* ora_board_new() { return new Board(); }
+void* ora_board_clone(void* h) { return new Board(*static_cast<Board*>(h)); }
+void ora_board_free(void* h) { delete static_cast<Board*>(h); }
+void ora_board_set(void* h, const char* fen) { static_cast<Board*>(h)->set(fen); }
+void ora_board_set_fen(void* h, int b, const char* fen) { static_cast<Board*>(h)->set_fen(b, fen); }
+// positions from a compact state; history restarts here (like Board::set_fen)
+void ora_board_from_compact(void* h, const hm_board* c) {
+    Board& bd = *static_cast<Board*>(h);
+    for (int b = 0; b < 2; ++b) {
+        bd.pos[b].from_compact(&c->pos[b]);
+        bd.states[b].clear();
+        bd.positionHistory[b].clear(); bd.positionHistoryPrefixes[b].clear(); bd.moveHistory[b].clear();
+        bd.record_position(b);
+    }
+}
+int ora_legal_moves(void* h, int b, uint32_t* out) {
+    return static_cast<Board*>(h)->pos[b].gen_legal(out);
+}
+void ora_push(void* h, int b, uint32_t m) { static_cast<Board*>(h)->push_move(b, m); }
+void ora_pop(void* h, int b) { static_cast<Board*>(h)->pop_move(b); }
+int ora_make_moves(void* h, uint32_t a, uint32_t b) {
+    try { static_cast<Board*>(h)->make_moves(a, b); } catch (const std::logic_error&) { return -1; }
+    return 0;
+}
+void ora_unmake_moves(void* h, uint32_t a, uint32_t b) { static_cast<Board*>(h)->unmake_moves(a, b); }
+int ora_is_checkmate(void* h, int side, int adv) { return static_cast<Board*>(h)->is_checkmate(side, adv != 0); }
+int ora_is_draw(void* h, int ply) { return static_cast<Board*>(h)->is_draw(ply); }
+uint64_t ora_hash_key(void* h, int adv) { return static_cast<Board*>(h)->hash_key(adv != 0); }
+uint64_t ora_rep_key(void* h, int b) { return static_cast<Board*>(h)->pos[b].rep_key(); }
+uint64_t ora_pos_key(void* h, int b) { return static_cast<Board*>(h)->pos[b].pos_key(); }
+int ora_repetition_count(void* h, int b) { return static_cast<Board*>(h)->repetition_count(b); }
+int ora_in_check(void* h, int b) { return static_cast<Board*>(h)->pos[b].checkers != 0; }
+int ora_gives_check(void* h, int b, uint32_t m) { return m != 0 && static_cast<Board*>(h)->pos[b].gives_check(m); }
+int ora_is_capture(void* h, int b, uint32_t m) { return static_cast<Board*>(h)->pos[b].is_capture(m); }
+void ora_compact(void* h, int team, int adv, hm_board* o) { static_cast<Board*>(h)->to_compact(o, team, adv != 0); }
+int ora_uci(void* h, int b, uint32_t m, char* buf, int cap) {
+    std::string s = uci_of(static_cast<Board*>(h)->pos[b], m);
+    std::strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0;
+    return (int)s.size();
+}
+uint64_t ora_perft(void* h, int depth) { return perft(*static_cast<Board*>(h), depth); }
+uint64_t ora_perft_fast(void* h, int depth) {
+    Board& b = *static_cast<Board*>(h);
+    return perft_fast(b.pos[0], b.pos[1], depth);
+}
+uint64_t ora_perft_single(void* h, int b, int depth) {
+    struct R { static uint64_t go(const Pos& p, int d) {
+        Move mv[1024]; int n = p.gen_legal(mv);
+        if (d == 1) return n;
+        uint64_t t = 0;
+        for (int i = 0; i < n; ++i) { Pos c = p; c.do_move(mv[i]); t += go(c, d - 1); }
+        return t; } };
+    return R::go(static_cast<Board*>(h)->pos[b], depth);
+}
+
+// compact-state entry points (no handle): what the GPU kernels are diffed against
+int ora_legal_moves_pos(const hm_pos* p, uint32_t* out) { Pos q; q.from_compact(p); return q.gen_legal(out); }
+void ora_planes(const hm_board* boards, size_t n, int dtype, void* out) {
+    for (size_t i = 0; i < n; ++i) {
+        if (dtype == HM_DT_F16) planes_f16(boards[i], static_cast<uint16_t*>(out) + i * HM_PLANE_VALUES);
+        else if (dtype == HM_DT_F32) planes_f32(boards[i], static_cast<float*>(out) + i * HM_PLANE_VALUES);
+        else planes_u8(boards[i], static_cast<uint8_t*>(out) + i * HM_PLANE_VALUES);
+    }
+}
+// Board::make_moves on compact states (history scalars: last_move updated, rep_count left to caller)
+void ora_make_moves_compact(const hm_board* in, uint32_t a, uint32_t b, hm_board* out) {
+    Pos A, B; A.from_compact(&in->pos[0]); B.from_compact(&in->pos[1]);
+    *out = *in;
+    if (a) { int h = A.do_move(a); if (h) B.add_to_hand(Pos::pc_color(h), Pos::pc_type(h)); out->last_move[0] = a; }
+    if (b) { int h = B.do_move(b); if (h) A.add_to_hand(Pos::pc_color(h), Pos::pc_type(h)); out->last_move[1] = b; }
+    A.to_compact(&out->pos[0]); B.to_compact(&out->pos[1]);
+}
+int ora_policy_index(uint32_t m, int stm) { return policy_index(m, stm); }
+void ora_policy_tables(int* normal, int* drop) {
+    std::memcpy(normal, T().polNormal, sizeof(T().polNormal));
+    std::memcpy(drop, T().polDrop, sizeof(T().polDrop));
+}
+int ora_policy_label(int idx, char* buf, int cap) {
+    const std::string& s = T().policy_labels[idx];
+    std::strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0;
+    return (int)s.size();
+}
+
+// SURVEY §8(d) synthetic workload: seeded random playouts (uniform board, uniform legal move,
+// <= maxPlies per game, restart on dead end); team/adv random bits.  Counter-based splitmix64
+// RNG so the device generator (hivemind_amd/csrc) can be checked against it draw for draw.
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+size_t ora_random_positions(uint64_t seed, size_t n, int maxPlies, hm_board* out) {
+    size_t produced = 0;
+    uint64_t game = 0;
+    while (produced < n) {
+        Board bd;
+        uint64_t ctr = 0;
+        auto rnd = [&]() { return splitmix64(seed ^ splitmix64(game * 0x10001ULL + (ctr++))); };
+        for (int ply = 0; ply < maxPlies && produced < n; ++ply) {
+            uint64_t r = rnd();
+            bd.to_compact(&out[produced++], (int)(r & 1), (int)((r >> 1) & 1));
+            int b = (int)((r >> 2) & 1);
+            Move mv[1024];
+            int nm = bd.pos[b].gen_legal(mv);
+            if (!nm) { b ^= 1; nm = bd.pos[b].gen_legal(mv); }
+            if (!nm) break;
+            bd.push_move(b, mv[(r >> 8) % (uint64_t)nm]);
+        }
+        ++game;
+    }
+    return produced;
+}
+
+// timing helpers for bench.py's cpu_baseline leg
+double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, int reps) {
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) ora_planes(boards, n, dtype, out);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // extern "C"

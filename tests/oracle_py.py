@@ -1,0 +1,166 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) and, when present, the reference
+build (oracle/_ref/libhmref.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libhmref.so")
+
+POS_DTYPE = np.dtype([
+    ("by_type", "<u8", (6,)), ("by_color", "<u8", (2,)), ("promoted", "<u8"), ("key", "<u8"),
+    ("hand", "u1", (2, 5)), ("castling", "u1"), ("ep", "u1"), ("stm", "u1"), ("rule50", "u1"),
+    ("game_ply", "<u2"),
+])
+BOARD_DTYPE = np.dtype([
+    ("pos", POS_DTYPE, (2,)), ("last_move", "<u4", (2,)), ("rep_count", "u1", (2,)),
+    ("team", "u1"), ("time_adv", "u1"), ("reserved", "<u4"),
+])
+DT = {"f16": 0, "f32": 1, "u8": 2}
+NPDT = {"f16": np.uint16, "f32": np.float32, "u8": np.uint8}
+
+if not os.path.exists(ORACLE_PATH):
+    import subprocess
+    subprocess.run(["make", "-s", "liboracle.so"], cwd=os.path.join(ROOT, "oracle"), check=True)
+lib = C.CDLL(ORACLE_PATH)
+ref = C.CDLL(REF_PATH) if os.path.exists(REF_PATH) else None
+
+_vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+
+
+def _sig(l, prefix):
+    s = {
+        "board_new": (_vp, []), "board_clone": (_vp, [_vp]), "board_free": (None, [_vp]),
+        "board_set": (None, [_vp, C.c_char_p]), "board_set_fen": (None, [_vp, _i, C.c_char_p]),
+        "legal_moves": (_i, [_vp, _i, _vp]), "push": (None, [_vp, _i, _u32]), "pop": (None, [_vp, _i]),
+        "make_moves": (_i, [_vp, _u32, _u32]), "unmake_moves": (None, [_vp, _u32, _u32]),
+        "is_checkmate": (_i, [_vp, _i, _i]), "is_draw": (_i, [_vp, _i]), "hash_key": (_u64, [_vp, _i]),
+        "pos_key": (_u64, [_vp, _i]), "repetition_count": (_i, [_vp, _i]), "in_check": (_i, [_vp, _i]),
+        "gives_check": (_i, [_vp, _i, _u32]), "is_capture": (_i, [_vp, _i, _u32]),
+        "compact": (None, [_vp, _i, _i, _vp]), "uci": (_i, [_vp, _i, _u32, C.c_char_p, _i]),
+        "perft": (_u64 if prefix == "ora_" else C.c_longlong, [_vp, _i]),
+        "perft_single": (_u64 if prefix == "ora_" else C.c_longlong, [_vp, _i, _i]),
+        "policy_tables": (None, [_vp, _vp]), "policy_label": (_i, [_i, C.c_char_p, _i]),
+    }
+    for name, (res, args) in s.items():
+        fn = getattr(l, prefix + name)
+        fn.restype, fn.argtypes = res, args
+
+
+_sig(lib, "ora_")
+lib.ora_board_from_compact.restype, lib.ora_board_from_compact.argtypes = None, [_vp, _vp]
+lib.ora_rep_key.restype, lib.ora_rep_key.argtypes = _u64, [_vp, _i]
+lib.ora_perft_fast.restype, lib.ora_perft_fast.argtypes = _u64, [_vp, _i]
+lib.ora_legal_moves_pos.restype, lib.ora_legal_moves_pos.argtypes = _i, [_vp, _vp]
+lib.ora_planes.restype, lib.ora_planes.argtypes = None, [_vp, C.c_size_t, _i, _vp]
+lib.ora_make_moves_compact.restype, lib.ora_make_moves_compact.argtypes = None, [_vp, _u32, _u32, _vp]
+lib.ora_policy_index.restype, lib.ora_policy_index.argtypes = _i, [_u32, _i]
+lib.ora_random_positions.restype, lib.ora_random_positions.argtypes = C.c_size_t, [_u64, C.c_size_t, _i, _vp]
+lib.ora_time_planes.restype, lib.ora_time_planes.argtypes = C.c_double, [_vp, C.c_size_t, _i, _vp, _i]
+if ref is not None:
+    ref.ref_init.restype = None
+    ref.ref_init()
+    _sig(ref, "ref_")
+    ref.ref_board_only_key.restype, ref.ref_board_only_key.argtypes = _u64, [_vp, _i]
+    ref.ref_fen.restype, ref.ref_fen.argtypes = _i, [_vp, _i, C.c_char_p, _i]
+    ref.ref_pw_allowed_children.restype, ref.ref_pw_allowed_children.argtypes = _i, [_i, _i]
+    ref.ref_get_cpuct.restype, ref.ref_get_cpuct.argtypes = C.c_float, [C.c_float]
+
+
+class Board:
+    """Handle over either implementation: Board(impl='ora'|'ref')."""
+
+    def __init__(self, impl="ora", fen=None):
+        self.l = lib if impl == "ora" else ref
+        self.p = impl + "_"
+        if self.l is None:
+            raise RuntimeError("reference build not available")
+        self.h = self._f("board_new")()
+        if fen:
+            self.set(fen)
+
+    def _f(self, name):
+        return getattr(self.l, self.p + name)
+
+    def __del__(self):
+        try:
+            self._f("board_free")(self.h)
+        except Exception:
+            pass
+
+    def from_compact(self, board):
+        board = np.ascontiguousarray(board)
+        lib.ora_board_from_compact(self.h, board.ctypes.data)
+
+    def set(self, fen): self._f("board_set")(self.h, fen.encode())
+    def set_fen(self, b, fen): self._f("board_set_fen")(self.h, b, fen.encode())
+
+    def legal_moves(self, b):
+        buf = np.zeros(1024, dtype=np.uint32)
+        n = self._f("legal_moves")(self.h, b, buf.ctypes.data)
+        return buf[:n].copy()
+
+    def push(self, b, m): self._f("push")(self.h, b, int(m))
+    def pop(self, b): self._f("pop")(self.h, b)
+    def make_moves(self, a, b): return self._f("make_moves")(self.h, int(a), int(b))
+    def unmake_moves(self, a, b): self._f("unmake_moves")(self.h, int(a), int(b))
+    def is_checkmate(self, side, adv=False): return bool(self._f("is_checkmate")(self.h, side, int(adv)))
+    def is_draw(self, ply=0): return bool(self._f("is_draw")(self.h, ply))
+    def hash_key(self, adv=False): return int(self._f("hash_key")(self.h, int(adv)))
+    def in_check(self, b): return bool(self._f("in_check")(self.h, b))
+    def repetition_count(self, b): return int(self._f("repetition_count")(self.h, b))
+    def perft(self, d): return int(self._f("perft")(self.h, d))
+    def perft_single(self, b, d): return int(self._f("perft_single")(self.h, b, d))
+
+    def compact(self, team=0, adv=False):
+        out = np.zeros(1, dtype=BOARD_DTYPE)
+        self._f("compact")(self.h, team, int(adv), out.ctypes.data)
+        return out
+
+    def uci(self, b, m):
+        buf = C.create_string_buffer(16)
+        self._f("uci")(self.h, b, int(m), buf, 16)
+        return buf.value.decode()
+
+    def find_move(self, b, uci):
+        for m in self.legal_moves(b):
+            if self.uci(b, m) == uci:
+                return int(m)
+        return 0
+
+
+def random_positions(seed, n, max_plies=120):
+    out = np.zeros(n, dtype=BOARD_DTYPE)
+    got = lib.ora_random_positions(seed, n, max_plies, out.ctypes.data)
+    assert got == n
+    return out
+
+
+def planes(boards, dtype="f16"):
+    boards = np.ascontiguousarray(boards)
+    out = np.zeros((len(boards), 4736), dtype=NPDT[dtype])
+    lib.ora_planes(boards.ctypes.data, len(boards), DT[dtype], out.ctypes.data)
+    return out
+
+
+def legal_moves_pos(pos):
+    pos = np.ascontiguousarray(pos)
+    buf = np.zeros(1024, dtype=np.uint32)
+    n = lib.ora_legal_moves_pos(pos.ctypes.data, buf.ctypes.data)
+    return buf[:n].copy()
+
+
+def make_moves_compact(board, a, b):
+    board = np.ascontiguousarray(board)
+    out = np.zeros(1, dtype=BOARD_DTYPE)
+    lib.ora_make_moves_compact(board.ctypes.data, int(a), int(b), out.ctypes.data)
+    return out
+
+
+def policy_tables(impl="ora"):
+    normal = np.zeros((2, 64, 64, 2), dtype=np.int32)
+    drop = np.zeros((2, 64, 8), dtype=np.int32)
+    (lib.ora_policy_tables if impl == "ora" else ref.ref_policy_tables)(normal.ctypes.data, drop.ctypes.data)
+    return normal, drop

@@ -1,0 +1,125 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden fixtures.  Bit-exact everywhere (integer / byte / index work; plane values are exactly
+representable)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fixture_boards():
+    d = np.load(os.path.join(G, "ref_playout.npz"))
+    return d, d["boards"].view(O.BOARD_DTYPE).reshape(-1)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32", "u8"])
+def test_planes_match_oracle(hm, dtype):
+    boards = np.concatenate([O.random_positions(42, 4096, 120), _fixture_boards()[1]])
+    got = hm.board_to_planes(hm.to_device(boards), dtype).cpu().numpy()
+    got = got.view(O.NPDT[dtype]).reshape(len(boards), -1)
+    want = O.planes(boards, dtype)
+    assert np.array_equal(got, want)
+
+
+def test_planes_edge_cases(hm):
+    import torch
+    # empty batch, batch of one, ragged batch sizes around the wave/block granularity
+    assert hm.board_to_planes(torch.empty((0, 208), dtype=torch.uint8, device="cuda")).shape[0] == 0
+    boards = O.random_positions(7, 1031, 200)
+    for n in (1, 3, 63, 64, 65, 255, 257, 1031):
+        got = hm.board_to_planes(hm.to_device(boards[:n]), "f16").cpu().numpy().view(np.uint16).reshape(n, -1)
+        assert np.array_equal(got, O.planes(boards[:n], "f16")), n
+    # maximum pockets / rule50 / repetition saturation
+    b = boards[:4].copy()
+    b["pos"]["hand"][:] = 17
+    b["pos"]["rule50"][:] = 200
+    b["rep_count"][:] = 3
+    for dt in ("f16", "f32", "u8"):
+        got = hm.board_to_planes(hm.to_device(b), dt).cpu().numpy().view(O.NPDT[dt]).reshape(4, -1)
+        assert np.array_equal(got, O.planes(b, dt))
+
+
+def test_planes_full_size_properties(hm):
+    """BASELINE config 2 size (65 536 positions): structural invariants + sampled equality."""
+    boards = O.random_positions(42, 65536, 120)
+    out = hm.board_to_planes(hm.to_device(boards), "f16")
+    p = out.view(len(boards), 74, 64)
+    import torch
+    one = torch.tensor(1.0, dtype=torch.float16, device="cuda")
+    assert bool((p[:, 26] == one).all()) and bool((p[:, 63] == one).all())        # constant planes
+    pieces = p[:, 0:12].float().sum(dim=(1, 2)).cpu().numpy()
+    want = np.array([bin(int(x)).count("1") for x in (boards["pos"]["by_color"][:, 0, 0] | boards["pos"]["by_color"][:, 0, 1])])
+    assert np.array_equal(pieces.astype(np.int64), want)                            # one bit per piece
+    idx = np.random.RandomState(0).choice(len(boards), 2048, replace=False)
+    got = out[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint16).reshape(len(idx), -1)
+    assert np.array_equal(got, O.planes(boards[idx], "f16"))
+
+
+def test_legal_moves_match_reference_fixture(hm):
+    d, boards = _fixture_boards()
+    pos = np.ascontiguousarray(boards["pos"].reshape(-1))          # [n*2] A,B interleaved
+    mv, cnt = hm.legal_moves(hm.to_device(pos))
+    mv, cnt = mv.cpu().numpy().astype(np.uint32), cnt.cpu().numpy()
+    offs, moves = d["offsets"], d["moves"]
+    for i in range(len(pos)):
+        want = moves[offs[i]:offs[i + 1]]
+        assert cnt[i] == len(want) and np.array_equal(mv[i, :cnt[i]], want), i   # order included
+    cc = hm.count_moves(hm.to_device(pos)).cpu().numpy()
+    assert np.array_equal(cc, cnt)
+
+
+def test_legal_moves_match_oracle_random(hm):
+    boards = O.random_positions(99, 6000, 300)
+    pos = np.ascontiguousarray(boards["pos"].reshape(-1))
+    mv, cnt = hm.legal_moves(hm.to_device(pos))
+    mv, cnt = mv.cpu().numpy().astype(np.uint32), cnt.cpu().numpy()
+    cc = hm.count_moves(hm.to_device(pos)).cpu().numpy()
+    for i in range(len(pos)):
+        want = O.legal_moves_pos(pos[i:i + 1])
+        assert cnt[i] == len(want) and np.array_equal(mv[i, :cnt[i]], want), i
+    assert np.array_equal(cc, cnt)
+
+
+def test_make_moves_match_oracle(hm):
+    import torch
+    boards = O.random_positions(5, 3000, 200)
+    rng = np.random.RandomState(3)
+    ma, mb, want = [], [], []
+    for i in range(len(boards)):
+        la = O.legal_moves_pos(boards["pos"][i:i + 1, 0])
+        lb = O.legal_moves_pos(boards["pos"][i:i + 1, 1])
+        a = int(la[rng.randint(len(la))]) if len(la) and rng.rand() > 0.1 else 0     # 0 = pass
+        b = int(lb[rng.randint(len(lb))]) if len(lb) and rng.rand() > 0.1 else 0
+        ma.append(a); mb.append(b)
+        want.append(O.make_moves_compact(boards[i:i + 1], a, b)[0])
+    want = np.array(want, dtype=O.BOARD_DTYPE)
+    got = hm.make_moves(hm.to_device(boards), torch.tensor(ma, dtype=torch.int32, device="cuda"),
+                        torch.tensor(mb, dtype=torch.int32, device="cuda"))
+    got = got.cpu().numpy().view(O.BOARD_DTYPE).reshape(-1)
+    assert got["pos"].tobytes() == want["pos"].tobytes()            # bitboards, hands, keys, counters
+    assert np.array_equal(got["last_move"], want["last_move"])
+
+
+def test_perft_bit_exact(hm):
+    p = json.load(open(os.path.join(G, "perft.json")))
+    for d, v in p["joint"].items():
+        assert hm.perft(int(d))[0] == v
+    assert hm.perft(4)[0] == p["joint_published"]["4"]
+    # stripes (multi-GPU sharding of the ply-2 frontier) add up
+    assert sum(hm.perft(3, shard=s, nshards=3)[0] for s in range(3)) == p["joint"]["3"]
+    assert hm.perft(0)[0] == 1
+
+
+def test_perft_from_midgame_matches_oracle(hm):
+    boards = O.random_positions(1234, 400, 80)
+    b = O.Board()
+    for i in (57, 133, 260, 399):
+        b.from_compact(boards[i:i + 1])
+        for d in (1, 2):
+            assert hm.perft(d, root=boards[i:i + 1])[0] == int(O.lib.ora_perft_fast(b.h, d)), (i, d)
