@@ -381,7 +381,18 @@ int grid_for(size_t n, int block, int maxBlocks = 2048) {
 
 }  // namespace
 
+const HostTables& hm_host_tables() { return g.host; }
+int hm_fail(int code, const std::string& msg) { return fail(code, msg); }
+
 extern "C" {
+
+void hm_search_config_default(hm_search_config* c) {   // search_params.h:26-273
+    if (!c) return;
+    c->cpuct_init = 2.5f; c->cpuct_base = 19652.0f; c->fpu_reduction = 1.0f; c->draw_contempt = 0.0f;
+    c->wdl_value_weight = 0.25f; c->moves_left_discount = 0.005f;
+    c->pw_coefficient = 2.0f; c->root_pw_coefficient = 4.0f; c->pw_exponent = 0.4f;
+    c->enable_transpositions = 1; c->enable_dynamic_fpu = 1; c->enable_wdl_eval = 1;
+}
 
 int hm_abi_version(void) { return 1; }
 const char* hm_last_error(void) { return t_err.c_str(); }

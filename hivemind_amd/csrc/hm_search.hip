@@ -1,0 +1,1669 @@
+// hm_search.hip — GPU-resident joint-action MCGS for many concurrent Bughouse games.
+//
+// Replaces, behind the C ABI of include/hivemind_amd.h (hm_sp_*), the reference's
+//   Agent::run_search node-budget path      search/agent.cc:421-558, 331-352
+//   SearchThread::{run_iteration, collect_batch, process_batch, select_and_expand,
+//                  canonicalize_child, backup} search/searchthread.cc:197-916
+//   Node (PUCT, PW gate, solver, reservations) search/node.h, node.cc:6-119
+//   JointCandidateGenerator                  environment/joint_action.h:126-359
+//   TranspositionTable (per search)          search/transposition_table.h:83-103
+//
+// MI355X-first design (not a port of the threaded CPU tree):
+//   * one wavefront owns one game: its tree lives in HBM pools private to the game (node pool,
+//     a bump arena for per-node edge arrays / candidate frontiers, an open-addressing TT), so
+//     there are no locks, no atomics and no shared_ptr: the reference's mutex / CAS protocols
+//     (virtual loss, evaluation reservations) become plain fields updated in program order.
+//   * all games advance in lockstep: collect (select+expand, virtual loss, terminal
+//     classification, leaf planes) -> one batched network call for every game's leaves ->
+//     process (movegen, masked softmax, sort, frontier seed, value shaping, backup, solver).
+//     The reference's double-buffered lookahead of one SearchThread (B=8) is reproduced per
+//     game, so per-game results equal the single-thread reference schedule.
+//   * PUCT child selection is lane-parallel (one edge per lane, wave arg-max with lowest-index
+//     tie break); repetition scans, policy gathers, the prior sort (rank sort) and the plane
+//     writer are lane-parallel too; the sequential tree logic runs wave-uniform.
+//   * libm-sensitive pieces are pinned: exp is a fixed IEEE sequence (hm_expf), cpuct(N) and the
+//     progressive-widening schedule come from host-built tables (std::log / std::pow, the
+//     reference's own expressions), Dirichlet gamma draws are made on the host with
+//     std::gamma_distribution<float> on std::mt19937_64 exactly as node.h:286-315.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "hm_rules_device.hpp"
+#include "hm_host.hpp"
+
+using namespace hmd;
+
+// provided by hm_kernels.hip
+const HostTables& hm_host_tables();
+int hm_fail(int code, const std::string& msg);
+
+namespace hms {
+
+constexpr int BATCH = 8;                 // SearchParams::BATCH_SIZE
+constexpr int MAX_TRAJ = 96;             // search path cap (root .. leaf)
+constexpr int HIST_GAME = 1024;          // game history keys per board
+constexpr int HIST_CAP = HIST_GAME + MAX_TRAJ + 8;
+constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
+constexpr int MAX_VISITS_TAB = 1 << 15;  // cpuct / PW tables
+constexpr int NLISTS = 8;                // LDS scratch move lists per wave
+constexpr float Q_INIT = -1.0f;
+
+enum : uint8_t { T_UNSOLVED = 0, T_WIN = 1, T_LOSS = 2, T_DRAW = 3 };
+enum : uint8_t { F_PENDING = 1, F_EXPANDED = 2 };
+enum : int { ST_IDLE = 0, ST_SEARCHING = 1, ST_FINISHING = 2, ST_DONE = 3, ST_NOACTION = 4, ST_ERROR = 5 };
+
+struct Edge {            // 40 B
+    int child;
+    float q, vsum, prior;
+    int visits, vloss;
+    u32 moveA, moveB;
+    uint16_t idxA, idxB;
+    uint8_t ctype, has_ctype, pad0, pad1;
+};
+struct Node {            // 64 B
+    u64 hash;
+    float valueSum;
+    int visits, vvsum, expanded, endInPly, unsolved, cntTypes;
+    u32 edges, edgeCap, gen;           // arena offsets (8-byte units), 0 = none
+    uint16_t depth;
+    uint8_t team, flags, type, pad;
+    u32 pad2;
+};
+struct HeapEnt { float prio; uint16_t iA, iB; };
+struct GenHdr {          // candidate generator state in the arena
+    int nA, nB;
+    u32 movesA, movesB, priorsA, priorsB;       // arena offsets; move bit 31 = capture flag
+    u32 heap, heapSize, heapCap;
+    u32 visited, visSize, visCap;
+    uint8_t aOn, bOn, adv, aCan, bCan, pad[3];
+};
+struct TrajEnt { int node, childIdx; u32 moveA, moveB; };
+struct Ctx {
+    int leaf, trajLen;
+    uint8_t team, sit, terminal, reserved;
+    float termValue;
+    u64 leafHash;
+    hm_pos pos[2];
+};
+struct Game {
+    // persistent game state (Board + selfplay bookkeeping)
+    hm_pos pos[2];
+    u32 lastMove[2];
+    int hlen[2];
+    u64 prefix[2];
+    int team, adv;
+    // search state
+    int status, root, nodeCount, nodesSearched, targetNodes, pending;
+    u32 arenaTop;
+    int ctxCount[2], validCount[2];
+    float alpha, eps;
+    u64 noiseSeed, rootHash;
+    int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
+    int nA_noise, nB_noise;
+};
+
+struct Params {          // device-visible configuration + pool geometry
+    int nGames, nodeCap, ttCap;        // ttCap power of two
+    u32 arenaCap;                      // 8-byte units
+    float cpuctInit, cpuctBase, fpuReduction, drawContempt, wdlWeight, mlDiscount;
+    int enableTranspositions, enableDynamicFpu, enableWdl;
+    float eps_unused;
+};
+
+struct Pools {
+    Game* games;
+    Node* nodes;          // [nGames][nodeCap]
+    u64* arena;           // [nGames][arenaCap]
+    u64* ttKeys;          // [nGames][ttCap]
+    int* ttVals;
+    Ctx* ctx;             // [nGames][2][BATCH]
+    TrajEnt* traj;        // [nGames][2][BATCH][MAX_TRAJ]
+    u64* hist;            // [nGames][2][HIST_CAP]
+    float* noise;         // [nGames][2][NOISE_CAP]
+    const float* cpuctTab;   // [MAX_VISITS_TAB]
+    const int* pwRoot;       // [MAX_VISITS_TAB]
+    const int* pwNode;
+    const RulesTab* rules;
+    const int* polNormal;    // [2][64][64][2]
+    const int* polDrop;      // [2][64][8]
+};
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// exp for x <= 0 from IEEE +,*,fma,rint only (identical copy: oracle/search.hpp portable_expf)
+__device__ __forceinline__ float hm_expf(float x) {
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 0.0f) x = 0.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(-n, 0.693145751953125f, x);
+    r = __builtin_fmaf(-n, 1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    p = __builtin_fmaf(p * r, r, r) + 1.0f;
+    int bits = __float_as_int(p);
+    bits += (int)n << 23;
+    return __int_as_float(bits);
+}
+__device__ __forceinline__ float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31;
+    uint32_t m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    return __int_as_float((int)x);
+}
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_int(v) & 0x7f800000) != 0x7f800000; }
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+
+struct G {               // per-wave view of one game's pools
+    Game* g;
+    Node* nodes;
+    u64* arena;
+    u64* ttKeys;
+    int* ttVals;
+    Ctx* ctx;
+    TrajEnt* traj;
+    u64* hist[2];
+    float* noise[2];
+    const Params* prm;
+    const Pools* pl;
+};
+__device__ __forceinline__ Edge* edges_of(const G& s, const Node& n) { return reinterpret_cast<Edge*>(s.arena + n.edges); }
+__device__ __forceinline__ GenHdr* gen_of(const G& s, const Node& n) { return reinterpret_cast<GenHdr*>(s.arena + n.gen); }
+
+// bump allocation in 8-byte units; offset 0 is reserved as "null"
+__device__ inline u32 arena_alloc(G& s, u32 bytes) {
+    const u32 units = (bytes + 7) >> 3;
+    const u32 top = s.g->arenaTop;
+    if (top + units > s.prm->arenaCap) { s.g->overflow |= 1; return 0; }
+    s.g->arenaTop = top + units;
+    return top;
+}
+__device__ inline int node_alloc(G& s, int team, int depth) {
+    const int id = s.g->nodeCount;
+    if (id >= s.prm->nodeCap) { s.g->overflow |= 2; return -1; }
+    s.g->nodeCount = id + 1;
+    Node n;
+    n.hash = 0; n.valueSum = 0.0f; n.visits = 0; n.vvsum = 0; n.expanded = 0; n.endInPly = 0; n.unsolved = 0; n.cntTypes = 0;
+    n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.pad = 0; n.pad2 = 0;
+    s.nodes[id] = n;
+    return id;
+}
+
+// ---- transposition table: insertOrGet (transposition_table.h:83-103) ----------------------
+__device__ inline int tt_insert_or_get(G& s, u64 hash, int node) {
+    const int cap = s.prm->ttCap;
+    u32 i = (u32)(hash ^ (hash >> 32)) & (cap - 1);
+    for (int probe = 0; probe < cap; ++probe) {
+        const int v = s.ttVals[i];
+        if (v < 0) {
+            if (s.g->ttCount * 2 >= cap) return node;        // table full: behave like a rejected insert
+            s.ttKeys[i] = hash; s.ttVals[i] = node; s.g->ttCount++;
+            return node;
+        }
+        if (s.ttKeys[i] == hash) return v;
+        i = (i + 1) & (cap - 1);
+    }
+    return node;
+}
+
+// ---- candidate generator (joint_action.h:126-359), strict total order --------------------
+__device__ __forceinline__ bool heap_before(const HeapEnt& a, const HeapEnt& b) {   // a pops before b
+    if (a.prio != b.prio) return a.prio > b.prio;
+    if (a.iA != b.iA) return a.iA < b.iA;
+    return a.iB < b.iB;
+}
+__device__ inline float joint_prior(const G& s, const GenHdr& h, int iA, int iB, u32* mA, u32* mB) {   // JointActionCandidate ctor :80-105
+    const u32 a = reinterpret_cast<const u32*>(s.arena + h.movesA)[iA], b = reinterpret_cast<const u32*>(s.arena + h.movesB)[iB];
+    const float pA = reinterpret_cast<const float*>(s.arena + h.priorsA)[iA], pB = reinterpret_cast<const float*>(s.arena + h.priorsB)[iB];
+    const u32 ma = a & 0x7fffffffu, mb = b & 0x7fffffffu;
+    const bool capA = a >> 31, capB = b >> 31;
+    const bool sitsA = ma == 0, sitsB = mb == 0;
+    bool invalid = false;
+    if (sitsA && sitsB) invalid = !is_double_sit_legal(h.adv, h.aOn, h.bOn);
+    else if (sitsA && h.aCan) invalid = !is_single_pass_legal(h.adv, h.aOn, h.bOn, capB);
+    else if (sitsB && h.bCan) invalid = !is_single_pass_legal(h.adv, h.aOn, h.bOn, capA);
+    if (mA) *mA = ma;
+    if (mB) *mB = mb;
+    return invalid ? -1.0f : pA * pB;
+}
+__device__ inline void gen_grow(G& s, u32& off, u32& cap, u32 size, u32 elemBytes) {
+    const u32 ncap = cap * 2;
+    const u32 noff = arena_alloc(s, ncap * elemBytes);
+    if (!noff) return;
+    const u32 words = (size * elemBytes + 7) >> 3;
+    for (u32 i = 0; i < words; ++i) s.arena[noff + i] = s.arena[off + i];
+    off = noff; cap = ncap;
+}
+__device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCandidate :146-177 (recursion -> explicit stack)
+    uint32_t stack[64];
+    int sp = 0;
+    stack[sp++] = ((u32)iA << 16) | (u32)iB;
+    while (sp > 0) {
+        const u32 key = stack[--sp];
+        const int a = key >> 16, b = key & 0xffff;
+        if (a >= h.nA || b >= h.nB) continue;
+        u32* vis = reinterpret_cast<u32*>(s.arena + h.visited);
+        bool seen = false;
+        for (u32 i = 0; i < h.visSize; ++i) seen |= vis[i] == key;
+        if (seen) continue;
+        if (h.visSize >= h.visCap) { gen_grow(s, h.visited, h.visCap, h.visSize, 4); vis = reinterpret_cast<u32*>(s.arena + h.visited); }
+        if (h.visSize >= h.visCap) return;
+        vis[h.visSize++] = key;
+        const float jp = joint_prior(s, h, a, b, nullptr, nullptr);
+        if (jp >= 0.0f) {
+            if (h.heapSize >= h.heapCap) gen_grow(s, h.heap, h.heapCap, h.heapSize, 8);
+            if (h.heapSize >= h.heapCap) return;
+            HeapEnt* hp = reinterpret_cast<HeapEnt*>(s.arena + h.heap);
+            HeapEnt e{jp, (uint16_t)a, (uint16_t)b};
+            u32 i = h.heapSize++;
+            while (i > 0) {                                   // sift up
+                const u32 par = (i - 1) >> 1;
+                if (!heap_before(e, hp[par])) break;
+                hp[i] = hp[par]; i = par;
+            }
+            hp[i] = e;
+        } else if (sp + 2 <= 64) {
+            // the reference recurses (iA+1,iB) first, then (iA,iB+1): push in reverse for LIFO
+            stack[sp++] = ((u32)a << 16) | (u32)(b + 1);
+            stack[sp++] = ((u32)(a + 1) << 16) | (u32)b;
+        }
+    }
+}
+__device__ inline bool gen_next(G& s, GenHdr& h, HeapEnt* out) {   // getNext :312-328
+    if (h.heapSize == 0) return false;
+    HeapEnt* hp = reinterpret_cast<HeapEnt*>(s.arena + h.heap);
+    const HeapEnt best = hp[0];
+    const HeapEnt last = hp[--h.heapSize];
+    u32 i = 0;
+    const u32 n = h.heapSize;
+    while (true) {                                            // sift down
+        u32 c = 2 * i + 1;
+        if (c >= n) break;
+        if (c + 1 < n && heap_before(hp[c + 1], hp[c])) ++c;
+        if (!heap_before(hp[c], last)) break;
+        hp[i] = hp[c]; i = c;
+    }
+    if (n > 0) hp[i] = last;
+    gen_push(s, h, best.iA + 1, best.iB);
+    gen_push(s, h, best.iA, best.iB + 1);
+    *out = best;
+    return true;
+}
+
+// ---- edges -------------------------------------------------------------------------------
+__device__ inline Edge* edge_append(G& s, Node& n) {
+    if (n.edgeCap == 0) {
+        n.edges = arena_alloc(s, 4 * sizeof(Edge)); n.edgeCap = n.edges ? 4 : 0;
+    } else if ((u32)n.expanded >= n.edgeCap) {
+        gen_grow(s, n.edges, n.edgeCap, (u32)n.expanded, sizeof(Edge));
+    }
+    if ((u32)n.expanded >= n.edgeCap) return nullptr;
+    return edges_of(s, n) + n.expanded;
+}
+
+// node.h:151-175
+__device__ inline bool should_expand_new_child(G& s, const Node& n) {
+    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    const Edge* e = edges_of(s, n);
+    bool allLose = n.expanded > 0;
+    bool anyUnvisited = false;
+    for (int i = 0; i < n.expanded; ++i) {
+        allLose &= s.nodes[e[i].child].type == T_WIN;
+        anyUnvisited |= (e[i].visits + e[i].vloss) == 0;
+    }
+    if (hasNext && allLose) return true;
+    if (anyUnvisited) return false;
+    int v = n.visits + n.vvsum;
+    if (v < 0) v = 0;
+    if (v >= MAX_VISITS_TAB) v = MAX_VISITS_TAB - 1;
+    const int allowed = n.depth == 0 ? s.pl->pwRoot[v] : s.pl->pwNode[v];
+    return hasNext && n.expanded < allowed;
+}
+
+// node.h:549-613
+__device__ inline void update_child_node_type(G& s, Node& n, int idx, uint8_t ct) {
+    if (n.type != T_UNSOLVED) return;
+    if (idx < 0 || idx >= n.cntTypes) return;
+    Edge* e = edges_of(s, n);
+    if (e[idx].ctype != T_UNSOLVED) return;
+    e[idx].ctype = ct;
+    n.unsolved--;
+    if (ct == T_LOSS) {
+        n.type = T_WIN;
+        n.endInPly = s.nodes[e[idx].child].endInPly + 1;
+        return;
+    }
+    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    if (n.unsolved == 0 && (n.flags & F_EXPANDED) && !hasNext) {
+        bool allWins = true, hasDrawn = false;
+        int longest = 0;
+        for (int i = 0; i < n.cntTypes; ++i) {
+            if (e[i].ctype != T_WIN) allWins = false;
+            if (e[i].ctype == T_DRAW) hasDrawn = true;
+            const int ep = s.nodes[e[i].child].endInPly;
+            if (ep > longest) longest = ep;
+        }
+        if (allWins) { n.type = T_LOSS; n.endInPly = longest + 1; }
+        else if (hasDrawn) n.type = T_DRAW;
+    }
+}
+
+// searchthread.cc:197-239
+__device__ inline void backup(G& s, const TrajEnt* tr, int len, float v) {
+    if (len <= 0) return;
+    uint8_t childType = s.nodes[tr[len - 1].node].type;
+    if (childType == T_WIN) v = 1.0f;
+    else if (childType == T_LOSS) v = -1.0f;
+    else if (childType == T_DRAW) v = s.nodes[tr[len - 1].node].team == s.nodes[tr[0].node].team ? -s.prm->drawContempt : s.prm->drawContempt;
+    for (int i = len - 1; i >= 0; --i) {
+        Node n = s.nodes[tr[i].node];
+        const int idx = tr[i].childIdx;
+        if (idx >= 0) {
+            Edge* e = edges_of(s, n) + idx;                    // update_and_remove_virtual_loss node.h:104-121
+            e->vloss--; n.vvsum--; e->visits++;
+            if (e->visits == 1) { e->vsum = v; e->q = v; }
+            else { e->vsum += v; e->q = e->vsum / (float)e->visits; }
+            n.valueSum += v; n.visits++;
+            if (childType != T_UNSOLVED) {
+                if (n.cntTypes < n.expanded) {                 // init_child_node_types :531-541
+                    Edge* all = edges_of(s, n);
+                    for (int k = n.cntTypes; k < n.expanded; ++k) all[k].ctype = T_UNSOLVED;
+                    n.unsolved += n.expanded - n.cntTypes;
+                    n.cntTypes = n.expanded;
+                }
+                update_child_node_type(s, n, idx, childType);
+                childType = n.type;
+            } else childType = T_UNSOLVED;
+        } else { n.valueSum += v; n.visits++; }                // update_terminal
+        s.nodes[tr[i].node] = n;
+        v = -v;
+    }
+}
+__device__ inline void cancel_virtual_losses(G& s, const TrajEnt* tr, int len) {   // :241-247
+    for (int i = 0; i < len; ++i)
+        if (tr[i].childIdx >= 0) {
+            Node& n = s.nodes[tr[i].node];
+            edges_of(s, n)[tr[i].childIdx].vloss--;
+            n.vvsum--;
+        }
+}
+
+// node.cc:6-119 — lane-parallel PUCT: lane i scores edge i (+64k), wave arg-max, lowest index wins ties.
+struct Sel { int child, idx; bool reserved; int pending; };
+__device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64* unavailMask /*LDS, 8 words*/) {
+    const int lane = threadIdx.x & 63;
+    Node n = s.nodes[nodeId];
+    const int limit = n.expanded;
+    if (limit == 0) return {-1, -1, false, -1};
+    Edge* e = edges_of(s, n);
+    int visits = n.visits + n.vvsum;
+    const float sqrtVisits = sqrtf((float)visits);
+    int vi = visits < 0 ? 0 : (visits >= MAX_VISITS_TAB ? MAX_VISITS_TAB - 1 : visits);
+    const float c = s.pl->cpuctTab[vi];
+    const float explorationBase = c * sqrtVisits;
+    float visitedPolicySum = 0.0f;
+    bool hasNonLosing = false;
+    // sequential (index-order) float sum: the reference adds childPriors in a plain loop
+    for (int i = 0; i < limit; ++i) {
+        if (s.prm->enableDynamicFpu && visits > 0 && e[i].visits + e[i].vloss > 0) visitedPolicySum += e[i].prior;
+        hasNonLosing |= s.nodes[e[i].child].type != T_WIN;
+    }
+    hasNonLosing &= n.type == T_UNSOLVED;
+    const float parentQ = visits > 0 ? (n.valueSum / (float)visits) : 0.0f;
+    const float fpuQ = (s.prm->enableDynamicFpu && visits > 0)
+        ? clampf(parentQ - s.prm->fpuReduction * sqrtf(fmaxf(0.0f, visitedPolicySum)), -1.0f, 1.0f) : Q_INIT;
+    for (int w = 0; w < 8; ++w) unavailMask[w] = 0;
+    int pending = -1;
+    while (true) {
+        float bestScore = -INFINITY;
+        int bestIdx = -1;
+        for (int base = 0; base < limit; base += 64) {
+            const int i = base + lane;
+            float score = -INFINITY;
+            bool ok = i < limit;
+            if (ok) {
+                const Edge ed = e[i];
+                if ((unavailMask[i >> 6] >> (i & 63)) & 1) ok = false;
+                else if (hasNonLosing && s.nodes[ed.child].type == T_WIN) ok = false;
+                else {
+                    const int vl = ed.vloss;
+                    const uint32_t ne = (uint32_t)ed.visits + (uint32_t)vl;
+                    float q;
+                    if (ne == 0) q = fpuQ;
+                    else if (vl == 0) q = ed.q;
+                    else q = (ed.vsum - (float)vl) / (float)ne;          // VIRTUAL_LOSS style
+                    const float u = explorationBase * ed.prior / (1.0f + (float)ne);
+                    score = q + u;
+                }
+            }
+            // wave arg-max of (score, lowest index).  `score > best` semantic: NaN / -inf never win.
+            float sc = ok ? score : -INFINITY;
+            int id = ok && sc > -INFINITY ? i : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) {
+                const float osc = __shfl_xor(sc, off);
+                const int oid = __shfl_xor(id, off);
+                if (osc > sc || (osc == sc && oid < id)) { sc = osc; id = oid; }
+            }
+            if (id != 0x7fffffff && sc > bestScore) { bestScore = sc; bestIdx = id; }
+        }
+        if (bestIdx < 0) return {-1, -1, false, pending};
+        const int child = e[bestIdx].child;
+        Node& cn = s.nodes[child];
+        bool reserved = false;
+        if (!(cn.flags & F_EXPANDED) && cn.type == T_UNSOLVED) {
+            if (cn.flags & F_PENDING) {                        // try_reserve_evaluation failed
+                pending = child;
+                unavailMask[bestIdx >> 6] |= 1ULL << (bestIdx & 63);
+                continue;
+            }
+            cn.flags |= F_PENDING;
+            reserved = true;
+        }
+        e[bestIdx].vloss++;
+        s.nodes[nodeId].vvsum = n.vvsum + 1;
+        return {child, bestIdx, reserved, -1};
+    }
+}
+
+// ---- search path bookkeeping (working board in registers, history keys in the game's pool) ---
+struct Path {
+    JBoard jb;
+    int len;                 // trajectory length
+};
+__device__ inline void path_reset(const G& s, Path& p) {
+    load_pos(p.jb.bd[0], &s.g->pos[0]);
+    load_pos(p.jb.bd[1], &s.g->pos[1]);
+    p.jb.hist[0] = s.hist[0]; p.jb.hist[1] = s.hist[1];
+    p.jb.hlen[0] = s.g->hlen[0]; p.jb.hlen[1] = s.g->hlen[1];
+    p.jb.prefix[0] = s.g->prefix[0]; p.jb.prefix[1] = s.g->prefix[1];
+    p.len = 0;
+}
+
+// searchthread.cc:741-806.  Returns: 0 = not expanded, 1 = expanded, 2 = pending (selection must abort).
+__device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, int parent, int idx, int& child, bool& reserved, bool rootAdv, int rootTeam, int* pendingOut) {
+    Node& c0 = s.nodes[child];
+    if (!s.prm->enableTranspositions) return (c0.flags & F_EXPANDED) ? 1 : 0;
+    if (c0.hash != 0) return (c0.flags & F_EXPANDED) ? 1 : 0;
+    const bool childAdv = c0.team == rootTeam ? rootAdv : !rootAdv;
+    const u64 h = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), childAdv, rt.zob.time_adv);
+    c0.hash = h;
+    const int canonical = tt_insert_or_get(s, h, child);
+    bool isAncestor = false;
+    for (int i = 0; i < p.len; ++i) isAncestor |= traj[i].node == canonical;
+    const bool teamMismatch = s.nodes[canonical].team != c0.team;
+    if (canonical == child || isAncestor || teamMismatch) return (c0.flags & F_EXPANDED) ? 1 : 0;
+    if (reserved) { c0.flags &= ~F_PENDING; reserved = false; }
+    edges_of(s, s.nodes[parent])[idx].child = canonical;       // replace_child
+    child = canonical;
+    Node& cn = s.nodes[canonical];
+    if (cn.flags & F_EXPANDED) return 1;
+    if (cn.type != T_UNSOLVED) return 0;
+    if (cn.flags & F_PENDING) {
+        Node& pn = s.nodes[parent];
+        edges_of(s, pn)[idx].vloss--; pn.vvsum--;             // remove_virtual_loss
+        *pendingOut = canonical;
+        return 2;
+    }
+    cn.flags |= F_PENDING;
+    reserved = true;
+    return 0;
+}
+
+// searchthread.cc:818-916.  Returns leaf node id or -1; traj/p updated.
+__device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, bool rootAdv, int rootTeam, bool* reservedOut, u64* unavailMask) {
+    int cur = s.g->root;
+    bool reserved = false;
+    traj[0] = TrajEnt{cur, -1, 0, 0};
+    p.len = 1;
+    while (true) {
+        Node n = s.nodes[cur];
+        if (n.type != T_UNSOLVED) break;
+        if (!(n.flags & F_EXPANDED)) {
+            if (!reserved) {
+                if (n.flags & F_PENDING) return -1;
+                s.nodes[cur].flags = n.flags | F_PENDING;
+                reserved = true;
+            }
+            break;
+        }
+        if (p.len >= MAX_TRAJ - 1) { s.g->overflow |= 4; return -1; }
+        int next = -1, childIdx = -1;
+        if (should_expand_new_child(s, n)) {
+            // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
+            GenHdr* gh = gen_of(s, n);
+            HeapEnt he;
+            if (gen_next(s, *gh, &he)) {
+                u32 ma, mb;
+                const float jp = joint_prior(s, *gh, he.iA, he.iB, &ma, &mb);
+                const int child = node_alloc(s, n.team ^ 1, n.depth + 1);
+                Node& nn = s.nodes[cur];
+                Edge* slot = child >= 0 ? edge_append(s, nn) : nullptr;
+                if (slot) {
+                    s.nodes[child].flags |= F_PENDING;
+                    *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 1, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
+                    nn.vvsum++;
+                    childIdx = nn.expanded;
+                    nn.expanded++;
+                    next = child;
+                    bool childReserved = true;
+                    jb_make(rt, p.jb, ma, mb, true);
+                    int pend = -1;
+                    const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, childReserved, rootAdv, rootTeam, &pend);
+                    if (cr == 2) return -1;
+                    traj[p.len - 1].childIdx = childIdx;
+                    traj[p.len] = TrajEnt{next, -1, ma, mb};
+                    p.len++;
+                    if (cr == 1) { cur = next; reserved = false; continue; }
+                    *reservedOut = childReserved;
+                    return next;
+                }
+                return -1;                                    // pool exhausted (overflow flagged)
+            }
+        }
+        const Sel sel = select_child_and_apply_virtual_loss(s, cur, unavailMask);
+        if (sel.child < 0 || sel.idx < 0) return -1;
+        next = sel.child; childIdx = sel.idx; reserved = sel.reserved;
+        const Edge ed = edges_of(s, s.nodes[cur])[childIdx];
+        jb_make(rt, p.jb, ed.moveA, ed.moveB, true);
+        int pend = -1;
+        const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, reserved, rootAdv, rootTeam, &pend);
+        if (cr == 2) return -1;
+        traj[p.len - 1].childIdx = childIdx;
+        traj[p.len] = TrajEnt{next, -1, ed.moveA, ed.moveB};
+        p.len++;
+        cur = next;
+    }
+    *reservedOut = reserved;
+    return cur;
+}
+
+// ---- leaf planes: wave-cooperative board_to_planes (fp16) for one hm_board in LDS ----------
+__device__ inline void write_planes_f16(const RulesTab& rt, const u64* bw /*26 words, LDS*/, uint4* dst, u64* s_mask, uint32_t* s_val) {
+    const int lane = threadIdx.x & 63;
+    const u64 tail = bw[25];
+    const int team = (int)((tail >> 16) & 0xff), adv = (int)((tail >> 24) & 0xff);
+    const uint32_t ONE = 0x3C00u;
+    for (int p = lane; p < HM_NB_PLANES; p += 64) {
+        const int b = p >= HM_NB_PLANES_PER_BOARD ? 1 : 0;
+        const int j = p - b * HM_NB_PLANES_PER_BOARD;
+        const u64* pw = bw + 12 * b;
+        const bool flip = b == 0 ? team == 1 : team == 0;
+        const int first = b == 0 ? team : team ^ 1;
+        const u64 t1 = pw[11];
+        const int castling = (int)((t1 >> 16) & 0xff), ep = (int)((t1 >> 24) & 0xff);
+        const int stm = (int)((t1 >> 32) & 0xff), r50 = (int)((t1 >> 40) & 0xff);
+        u64 mask = ~0ULL;
+        uint32_t val = ONE;
+        bool orient = false;
+        if (j < 12) { const int c = j < 6 ? first : first ^ 1; mask = pw[j < 6 ? j : j - 6] & pw[6 + c]; orient = true; }
+        else if (j < 22) {
+            const int c = j < 17 ? first : first ^ 1, k = j < 17 ? j - 12 : j - 17;
+            const int byteIdx = 80 + c * 5 + k;
+            const int cnt = (int)((pw[byteIdx >> 3] >> (8 * (byteIdx & 7))) & 0xff);
+            val = rt.pocket_f16[cnt & 63];
+        } else if (j < 24) { const int c = j == 22 ? first : first ^ 1; mask = pw[8] & pw[6 + c]; orient = true; }
+        else if (j == 24) { mask = ep < 64 ? bit(ep) : 0; orient = true; }
+        else if (j == 25) val = stm == first ? ONE : 0;
+        else if (j == 26) {}
+        else if (j < 31) { const int c = j < 29 ? first : first ^ 1; const int right = ((j - 27) & 1) ? (c == 0 ? 2 : 8) : (c == 0 ? 1 : 4); val = (castling & right) ? ONE : 0; }
+        else if (j == 31) val = adv ? ONE : 0;
+        else if (j < 34) {
+            const uint32_t lm = (uint32_t)(bw[24] >> (32 * b));
+            mask = 0;
+            if (lm != 0) {
+                const bool drop = (lm & (15u << 12)) == HM_MT_DROP;
+                int sq = j == 32 ? (int)((lm >> 6) & 63) : (int)(lm & 63);
+                if (flip) sq ^= 56;
+                if (!(j == 32 && drop)) mask = bit(sq);
+            }
+        } else if (j == 34) val = rt.r50_f16[r50 > 50 ? 50 : r50];
+        else { const int rc = (int)((tail >> (8 * b)) & 0xff); val = rc >= (j == 35 ? 2 : 3) ? ONE : 0; }
+        if (orient && flip) mask = __builtin_bswap64(mask);
+        s_mask[p] = mask; s_val[p] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < HM_PLANE_VALUES / 8; c += 64) {
+        const int sq0 = c * 8, p = sq0 >> 6;
+        const uint32_t b = (uint32_t)(s_mask[p] >> (sq0 & 63)) & 0xff, v = s_val[p];
+        uint4 o;
+        o.x = ((b & 1) ? v : 0) | ((b & 2) ? v << 16 : 0);
+        o.y = ((b & 4) ? v : 0) | ((b & 8) ? v << 16 : 0);
+        o.z = ((b & 16) ? v : 0) | ((b & 32) ? v << 16 : 0);
+        o.w = ((b & 64) ? v : 0) | ((b & 128) ? v << 16 : 0);
+        dst[c] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveLds {
+    u32 lists[NLISTS][HM_MAX_MOVES];
+    float priors[2][HM_MAX_MOVES + 8];
+    u64 board[26];
+    u64 pmask[HM_NB_PLANES + 6];
+    uint32_t pval[HM_NB_PLANES + 6];
+    u64 unavail[8];
+    TrajEnt traj[MAX_TRAJ];
+};
+
+__device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
+    G s;
+    s.g = pl.games + g;
+    s.nodes = pl.nodes + (size_t)g * prm.nodeCap;
+    s.arena = pl.arena + (size_t)g * prm.arenaCap;
+    s.ttKeys = pl.ttKeys + (size_t)g * prm.ttCap;
+    s.ttVals = pl.ttVals + (size_t)g * prm.ttCap;
+    s.ctx = pl.ctx + (size_t)g * 2 * BATCH;
+    s.traj = pl.traj + (size_t)g * 2 * BATCH * MAX_TRAJ;
+    s.hist[0] = pl.hist + ((size_t)g * 2 + 0) * HIST_CAP;
+    s.hist[1] = pl.hist + ((size_t)g * 2 + 1) * HIST_CAP;
+    s.noise[0] = pl.noise + ((size_t)g * 2 + 0) * NOISE_CAP;
+    s.noise[1] = pl.noise + ((size_t)g * 2 + 1) * NOISE_CAP;
+    s.prm = &prm; s.pl = &pl;
+    return s;
+}
+
+// process of one context list (searchthread.cc:444-639).  outs == nullptr for terminal-only batches.
+struct NetOut { const uint16_t *value, *piA, *piB, *wdl, *ml; };
+
+__device__ inline void expand_leaf(G& s, const RulesTab& rt, WaveLds& L, const Ctx& ctx, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
+    const int lane = threadIdx.x & 63;
+    P bd[2];
+    load_pos(bd[0], &ctx.pos[0]);
+    load_pos(bd[1], &ctx.pos[1]);
+    const int team = ctx.team;
+    const bool leafAdv = team == rootTeam ? rootAdv : !rootAdv;
+    const bool aOn = (int)bd[0].stm == team, bOn = (int)bd[1].stm == (team ^ 1);
+    // legal moves of the on-turn boards: lane 0 -> A, lane 1 -> B (same code path, no divergence)
+    int cntMine = 0;
+    if (lane < 2) {
+        const bool on = lane == 0 ? aOn : bOn;
+        if (on) {
+            u32* list = L.lists[lane];
+            int n = gen_legal(rt.att, bd[lane], list);
+            int k = 0;
+            for (int i = 0; i < n; ++i) {                      // erase R/B under-promotions (utils.h:169-182), order kept
+                const u32 m = list[i];
+                const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
+                if (!bad) list[k++] = m;
+            }
+            cntMine = k;
+        }
+    }
+    int nReal[2];
+    nReal[0] = __shfl(cntMine, 0); nReal[1] = __shfl(cntMine, 1);
+    __builtin_amdgcn_wave_barrier();
+    int nAct[2];
+    for (int b = 0; b < 2; ++b) {
+        u32* list = L.lists[b];
+        float* pr = L.priors[b];
+        const int n = nReal[b];
+        list[n] = 0;                                           // MOVE_NONE appended last
+        nAct[b] = n + 1;
+        __builtin_amdgcn_wave_barrier();
+        if (n == 0) { pr[0] = 1.0f; __builtin_amdgcn_wave_barrier(); continue; }
+        // get_normalized_probability (utils.h:226-243): gather fp16 logits through the policy tables
+        const uint16_t* pol = b == 0 ? piA : piB;
+        const int stm = (int)bd[b].stm;
+        float mx = -INFINITY;
+        for (int i = lane; i < n + 1; i += 64) {
+            const u32 m = list[i];
+            int idx;
+            if (m == 0) idx = 0;
+            else if ((m & (15u << 12)) == HM_MT_DROP) idx = s.pl->polDrop[(stm * 64 + (m & 63)) * 8 + ((m >> 16) & 63)];
+            else {
+                const int f = (m >> 6) & 63, to = m & 63;
+                const int knight = ((m & (15u << 12)) == HM_MT_PROMOTION && ((m >> 16) & 63) == HM_KNIGHT) ? 1 : 0;
+                idx = s.pl->polNormal[((stm * 64 + f) * 64 + to) * 2 + knight];
+            }
+            const float lg = idx >= 0 ? h2f(pol[idx]) : -INFINITY;
+            pr[i] = lg;
+            if (finite_f(lg)) mx = fmaxf(mx, lg);
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        __builtin_amdgcn_wave_barrier();
+        if (!finite_f(mx)) {                                   // normalize_logits fallback :136-141
+            for (int i = lane; i < n + 1; i += 64) pr[i] = 1.0f / (float)(n + 1);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        for (int i = lane; i < n + 1; i += 64) { const float lg = pr[i]; pr[i] = finite_f(lg) ? hm_expf(lg - mx) : 0.0f; }
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;                                      // index-order double sum, as the reference
+        for (int i = 0; i < n + 1; ++i) sum += (double)pr[i];
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n + 1; i += 64) pr[i] = (float)((double)pr[i] / sum);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // root Dirichlet noise (node.h:286-315): gamma draws were made on the host
+    Node leaf = s.nodes[ctx.leaf];
+    if (leaf.depth == 0 && s.g->alpha > 0.0f && s.g->eps > 0.0f) {
+        for (int b = 0; b < 2; ++b) {
+            const int n = nAct[b];
+            if (n <= 1) continue;
+            float* pr = L.priors[b];
+            const float* nz = s.noise[b];
+            float total = 0.0f;
+            for (int i = 0; i < n && i < NOISE_CAP; ++i) total += nz[i];
+            if (total <= 0.0f) continue;
+            const float eps = clampf(s.g->eps, 0.0f, 1.0f);
+            for (int i = lane; i < n; i += 64) pr[i] = (1.0f - eps) * pr[i] + eps * nz[i < NOISE_CAP ? i : NOISE_CAP - 1] / total;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // JointCandidateGenerator::initialize (joint_action.h:195-278): rank sort by (prior desc, index asc)
+    const u32 genOff = arena_alloc(s, sizeof(GenHdr));
+    if (!genOff) return;
+    GenHdr h;
+    h.nA = nAct[0]; h.nB = nAct[1];
+    h.aOn = aOn; h.bOn = bOn; h.adv = leafAdv;
+    h.aCan = aOn && nReal[0] > 0; h.bCan = bOn && nReal[1] > 0;
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    u32 offM[2], offP[2];
+    for (int b = 0; b < 2; ++b) {
+        offM[b] = arena_alloc(s, (u32)nAct[b] * 4);
+        offP[b] = arena_alloc(s, (u32)nAct[b] * 4);
+    }
+    h.heapCap = 16; h.heapSize = 0; h.heap = arena_alloc(s, h.heapCap * 8);
+    h.visCap = 32; h.visSize = 0; h.visited = arena_alloc(s, h.visCap * 4);
+    if (!offM[0] || !offP[0] || !offM[1] || !offP[1] || !h.heap || !h.visited) return;
+    for (int b = 0; b < 2; ++b) {
+        const int n = nAct[b];
+        const u32* list = L.lists[b];
+        const float* pr = L.priors[b];
+        u32* outM = reinterpret_cast<u32*>(s.arena + offM[b]);
+        float* outP = reinterpret_cast<float*>(s.arena + offP[b]);
+        for (int i = lane; i < n; i += 64) {
+            const float pi = pr[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) { const float pj = pr[j]; rank += (pj > pi) || (pj == pi && j < i); }
+            const u32 m = list[i];
+            const u32 cap = (m != 0 && is_capture(bd[b], m)) ? 0x80000000u : 0u;
+            outM[rank] = m | cap;
+            outP[rank] = pi;
+        }
+    }
+    wave_fence();
+    h.movesA = offM[0]; h.movesB = offM[1]; h.priorsA = offP[0]; h.priorsB = offP[1];
+    gen_push(s, h, 0, 0);
+    if (h.heapSize == 0) { gen_push(s, h, 1, 0); gen_push(s, h, 0, 1); }
+    leaf.gen = genOff;
+    leaf.expanded = 0;
+    // first child (try_init_and_expand node.h:317-341)
+    HeapEnt he;
+    if (gen_next(s, h, &he)) {
+        u32 ma, mb;
+        const float jp = joint_prior(s, h, he.iA, he.iB, &ma, &mb);
+        const int child = node_alloc(s, leaf.team ^ 1, leaf.depth + 1);
+        Edge* slot = child >= 0 ? edge_append(s, leaf) : nullptr;
+        if (slot) {
+            *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 0, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
+            leaf.expanded = 1;
+            leaf.flags |= F_EXPANDED;
+        }
+    }
+    *reinterpret_cast<GenHdr*>(s.arena + genOff) = h;
+    s.nodes[ctx.leaf] = leaf;
+}
+
+__device__ inline float shape_value(const G& s, uint16_t valueH, const uint16_t* wdl, uint16_t mlH) {   // searchthread.cc:569-619
+    const float bv = h2f(valueH);
+    const float scalar = finite_f(bv) ? clampf(bv, -1.0f, 1.0f) : 0.0f;
+    float nv = scalar;
+    if (s.prm->enableWdl) {
+        const float l = h2f(wdl[0]), d = h2f(wdl[1]), w = h2f(wdl[2]);
+        if (finite_f(l) && finite_f(d) && finite_f(w)) {
+            const float mx = fmaxf(l, fmaxf(d, w));
+            const float el = hm_expf(l - mx), ed = hm_expf(d - mx), ew = hm_expf(w - mx);
+            const float sum = el + ed + ew;
+            if (finite_f(sum) && sum > 0.0f) {
+                const float pl = el / sum, pd = ed / sum, pw = ew / sum;
+                const float wv = pw - pl - s.prm->drawContempt * pd;
+                const float ww = clampf(s.prm->wdlWeight, 0.0f, 1.0f);
+                nv = (1.0f - ww) * scalar + ww * wv;
+            }
+        }
+    }
+    if (s.prm->mlDiscount > 0.0f) {
+        const float np = clampf(h2f(mlH), 0.0f, 1.0f);
+        const float disc = clampf(s.prm->mlDiscount, 0.0f, 1.0f);
+        nv *= 1.0f - disc * np;
+    }
+    return clampf(nv, -1.0f, 1.0f);
+}
+
+__device__ inline void process_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+    const int n = s.g->ctxCount[buf];
+    int inf = 0;
+    for (int i = 0; i < n; ++i) {
+        Ctx& ctx = s.ctx[buf * BATCH + i];
+        const TrajEnt* tr = s.traj + (size_t)(buf * BATCH + i) * MAX_TRAJ;
+        if (ctx.terminal) {
+            if (ctx.reserved) s.nodes[ctx.leaf].flags &= ~F_PENDING;
+            backup(s, tr, ctx.trajLen, ctx.termValue);
+            continue;
+        }
+        if (s.nodes[ctx.leaf].type != T_UNSOLVED) {
+            s.nodes[ctx.leaf].flags &= ~F_PENDING;
+            backup(s, tr, ctx.trajLen, 0.0f);
+            inf++;
+            continue;
+        }
+        const int row = rowBase + inf;
+        if (ctx.leafHash != 0) s.nodes[ctx.leaf].hash = ctx.leafHash;
+        if (!(s.nodes[ctx.leaf].flags & F_EXPANDED))
+            expand_leaf(s, rt, L, ctx, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
+        s.nodes[ctx.leaf].flags &= ~F_PENDING;
+        const float nv = shape_value(s, out->value[row], out->wdl + (size_t)row * 3, out->ml[row]);
+        backup(s, tr, ctx.trajLen, nv);
+        inf++;
+    }
+    s.g->nodesSearched += n;
+    s.g->ctxCount[buf] = 0;
+    s.g->validCount[buf] = 0;
+}
+__device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
+    const int n = s.g->ctxCount[buf];
+    int done = 0;
+    for (int i = 0; i < n; ++i) {
+        Ctx& ctx = s.ctx[buf * BATCH + i];
+        const TrajEnt* tr = s.traj + (size_t)(buf * BATCH + i) * MAX_TRAJ;
+        if (ctx.reserved) s.nodes[ctx.leaf].flags &= ~F_PENDING;
+        if (ctx.terminal) { backup(s, tr, ctx.trajLen, ctx.termValue); done++; }
+        else cancel_virtual_losses(s, tr, ctx.trajLen);
+    }
+    s.g->nodesSearched += done;
+    s.g->ctxCount[buf] = 0;
+    s.g->validCount[buf] = 0;
+}
+
+// collect_batch (searchthread.cc:255-442).  Planes of NN leaves go to planesOut + slot*4736 (fp16).
+__device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, uint16_t* planesOut) {
+    const int lane = threadIdx.x & 63;
+    int nctx = 0, valid = 0, attempts = 0;
+    Path p;
+    while (nctx < BATCH && attempts < BATCH * 2) {
+        attempts++;
+        path_reset(s, p);
+        bool reserved = false;
+        const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
+        if (leaf < 0) {
+            s.g->reservationCollisions++;
+            cancel_virtual_losses(s, L.traj, p.len);
+            continue;
+        }
+        bool collision = false;
+        for (int i = 0; i < nctx; ++i) collision |= s.ctx[buf * BATCH + i].leaf == leaf;
+        if (collision) {
+            s.g->sameBatchCollisions++;
+            if (reserved) s.nodes[leaf].flags &= ~F_PENDING;
+            cancel_virtual_losses(s, L.traj, p.len);
+            continue;
+        }
+        Ctx ctx;
+        ctx.leaf = leaf; ctx.trajLen = p.len; ctx.reserved = reserved;
+        ctx.team = s.nodes[leaf].team;
+        ctx.sit = ((ctx.team == rootTeam) == rootAdv) ? 1 : 0;
+        ctx.terminal = 0; ctx.termValue = 0.0f; ctx.leafHash = 0;
+        const int searchPly = p.len - 1;
+        if (searchPly > s.g->maxDepth) s.g->maxDepth = searchPly;
+        const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
+        const uint8_t solved = s.nodes[leaf].type;
+        bool keep = true;
+        if (solved != T_UNSOLVED) {
+            ctx.terminal = 1;
+            ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
+        } else {
+            int endInPly = 0;
+            const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
+            if (to != 0) {
+                ctx.terminal = 1;
+                Node& ln = s.nodes[leaf];
+                if (to == 1) { ctx.termValue = 1.0f; ln.type = T_WIN; ln.valueSum = 1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
+                else if (to == 2) { ctx.termValue = -1.0f; ln.type = T_LOSS; ln.valueSum = -1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
+                else { ctx.termValue = drawValue; ln.type = T_DRAW; ln.endInPly = 1; }
+            } else if (!ctx.reserved) {
+                s.g->reservationCollisions++;
+                cancel_virtual_losses(s, L.traj, p.len);
+                keep = false;
+            } else {
+                const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
+                ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
+                store_pos(&ctx.pos[0], p.jb.bd[0]);
+                store_pos(&ctx.pos[1], p.jb.bd[1]);
+                // hm_board image in LDS for the plane writer
+                wave_fence();
+                hm_board* hb = reinterpret_cast<hm_board*>(L.board);
+                if (lane == 0) {
+                    hb->pos[0] = ctx.pos[0]; hb->pos[1] = ctx.pos[1];
+                    // last move per board: deepest path move on that board, else the game's last move
+                    u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
+                    for (int i = 1; i < p.len; ++i) { if (L.traj[i].moveA) lm[0] = L.traj[i].moveA; if (L.traj[i].moveB) lm[1] = L.traj[i].moveB; }
+                    hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
+                    for (int b = 0; b < 2; ++b) { int rc = repetition_count(hist_of(p.jb, b)); hb->rep_count[b] = (uint8_t)(rc > 3 ? 3 : rc); }
+                    hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
+                }
+                wave_fence();
+                write_planes_f16(rt, L.board, reinterpret_cast<uint4*>(planesOut + (size_t)valid * HM_PLANE_VALUES), L.pmask, L.pval);
+                valid++;
+            }
+        }
+        if (keep) {
+            s.ctx[buf * BATCH + nctx] = ctx;
+            TrajEnt* dst = s.traj + (size_t)(buf * BATCH + nctx) * MAX_TRAJ;
+            for (int i = lane; i < p.len; i += 64) dst[i] = L.traj[i];
+            wave_fence();
+            nctx++;
+        }
+    }
+    s.g->ctxCount[buf] = nctx;
+    s.g->validCount[buf] = valid;
+    s.g->evalRows += valid;
+}
+
+// =======================================================================================
+// kernels (one wave / block of 64 threads per game)
+// =======================================================================================
+__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesCur, uint16_t* planesNext) {
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x;
+    G s = make_view(pl, prm, g);
+    if (s.g->status != ST_SEARCHING) return;
+    const int rootTeam = s.g->team;
+    const bool rootAdv = s.g->adv != 0;
+    uint16_t* cur = planesCur + (size_t)g * BATCH * HM_PLANE_VALUES;
+    uint16_t* nxt = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
+    // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
+    while (s.g->pending < 0) {
+        if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
+        collect_batch(s, s_rt, L, 0, rootTeam, rootAdv, cur);
+        if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return; }   // no progress possible
+        if (s.g->validCount[0] == 0) { process_batch(s, s_rt, L, 0, rootTeam, rootAdv, nullptr, 0); continue; }
+        s.g->pending = 0;
+        collect_batch(s, s_rt, L, 1, rootTeam, rootAdv, nxt);
+        return;
+    }
+    if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
+    collect_batch(s, s_rt, L, 1 - s.g->pending, rootTeam, rootAdv, nxt);
+}
+
+__global__ __launch_bounds__(64) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x;
+    G s = make_view(pl, prm, g);
+    const int st = s.g->status;
+    if (st != ST_SEARCHING && st != ST_FINISHING) return;
+    const int rootTeam = s.g->team;
+    const bool rootAdv = s.g->adv != 0;
+    const int rowBase = g * BATCH;
+    if (st == ST_FINISHING) {
+        // finish_pending_iteration / discard_pending_iteration (agent.cc:343-352)
+        if (s.g->pending >= 0) {
+            const int done = s.g->pending;
+            s.g->pending = -1;
+            if (s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) abort_batch(s, done);
+            else process_batch(s, s_rt, L, done, rootTeam, rootAdv, &out, rowBase);
+        }
+        s.g->status = s.g->overflow ? ST_ERROR : ST_DONE;
+        return;
+    }
+    if (s.g->pending < 0) { if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1); return; }
+    const int done = s.g->pending, look = 1 - done;
+    s.g->pending = -1;
+    process_batch(s, s_rt, L, done, rootTeam, rootAdv, &out, rowBase);
+    if (s.g->validCount[look] == 0) process_batch(s, s_rt, L, look, rootTeam, rootAdv, nullptr, 0);
+    else s.g->pending = look;
+    if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
+}
+
+// Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
+__global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* targetNodes, const u64* noiseSeeds, float alpha, float eps, const uint8_t* searchMask, u64* rootHashOut) {
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    if (searchMask && !searchMask[g]) { s.g->status = ST_IDLE; rootHashOut[g] = 0; return; }
+    const RulesTab& rt = s_rt;
+    for (int i = lane; i < prm.ttCap; i += 64) s.ttVals[i] = -1;
+    wave_fence();
+    Game& gm = *s.g;
+    gm.nodeCount = 0; gm.arenaTop = 1; gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
+    gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
+    gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
+    gm.targetNodes = targetNodes[g]; gm.noiseSeed = noiseSeeds ? noiseSeeds[g] : 0; gm.alpha = alpha; gm.eps = eps;
+    gm.root = -1;
+    Path p;
+    path_reset(s, p);
+    const int team = gm.team;
+    const bool adv = gm.adv != 0;
+    u32* scratch = &L.lists[0][0];
+    const bool aOn = (int)p.jb.bd[0].stm == team, bOn = (int)p.jb.bd[1].stm == (team ^ 1);
+    const bool canWait = is_double_sit_legal(adv, aOn, bOn);
+    const u64 rootHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), adv, rt.zob.time_adv);
+    gm.rootHash = rootHash;
+    rootHashOut[g] = rootHash;
+    const bool mateUs = is_checkmate(rt, p.jb.bd, team, adv, scratch);
+    if (is_checkmate(rt, p.jb.bd, team ^ 1, !adv, scratch) || mateUs || jb_is_draw(p.jb, 0)) { gm.status = ST_NOACTION; return; }
+    const int cA = aOn ? count_legal(rt.att, p.jb.bd[0]) : 0, cB = bOn ? count_legal(rt.att, p.jb.bd[1]) : 0;
+    if (cA + cB == 0 && !canWait) { gm.status = ST_NOACTION; return; }
+    // ---- find_immediate_root_mate (agent.cc:136-238)
+    {
+        u32* la = L.lists[6];
+        u32* lb = L.lists[7];
+        int nA = aOn ? gen_legal(rt.att, p.jb.bd[0], la) : 0;
+        int nB = bOn ? gen_legal(rt.att, p.jb.bd[1], lb) : 0;
+        const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;
+        // stable_partition: checking moves first (order within each class kept)
+        for (int b = 0; b < 2; ++b) {
+            u32* l = b == 0 ? la : lb;
+            const int n = b == 0 ? nA : nB;
+            u32* tmp = L.lists[5];
+            int k = 0;
+            for (int i = 0; i < n; ++i) if (gives_check(rt, p.jb.bd[b], l[i])) tmp[k++] = l[i];
+            for (int i = 0; i < n; ++i) if (!gives_check(rt, p.jb.bd[b], l[i])) tmp[k++] = l[i];
+            for (int i = 0; i < n; ++i) l[i] = tmp[i];
+        }
+        bool found = false;
+        u32 fa = 0, fb = 0;
+        for (int b = 0; b < 2 && !found; ++b) {
+            const bool on = b == 0 ? aOn : bOn, otherOn = b == 0 ? bOn : aOn;
+            if (!on) continue;
+            const u32* l = b == 0 ? la : lb;
+            const int n = b == 0 ? nA : nB;
+            for (int i = 0; i < n && !found; ++i) {
+                const u32 m = l[i];
+                if (!aChk && !bChk && !gives_check(rt, p.jb.bd[b], m)) continue;
+                const bool cap = is_capture(p.jb.bd[b], m);
+                if (!otherOn || is_single_pass_legal(adv, aOn, bOn, cap)) {
+                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                    const int h = do_move(rt.att, rt.zob, nb[b], m);
+                    if (h) add_to_hand(rt.zob, nb[1 - b], h);
+                    if (is_checkmate(rt, nb, team ^ 1, !adv, scratch)) { found = true; if (b == 0) fa = m; else fb = m; }
+                }
+            }
+        }
+        if (!found && aOn && bOn) {
+            for (int i = 0; i < nA && !found; ++i) {
+                const u32 mA = la[i];
+                const bool chkA = gives_check(rt, p.jb.bd[0], mA);
+                for (int j = 0; j < nB && !found; ++j) {
+                    const u32 mB = lb[j];
+                    if (!aChk && !bChk && !chkA && !gives_check(rt, p.jb.bd[1], mB)) continue;
+                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                    make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
+                    if (is_checkmate(rt, nb, team ^ 1, !adv, scratch)) { found = true; fa = mA; fb = mB; }
+                }
+            }
+        }
+        if (found) {   // agent.cc:458-499: trivial proven tree
+            const int root = node_alloc(s, team, 0);
+            const int child = node_alloc(s, team ^ 1, 1);
+            Node rn = s.nodes[root];
+            rn.hash = rootHash;
+            Edge* slot = edge_append(s, rn);
+            *slot = Edge{child, 1.0f, 1.0f, 1.0f, 1, 0, fa, fb, 0, 0, T_LOSS, 0, 0, 0};
+            rn.expanded = 1; rn.flags |= F_EXPANDED; rn.cntTypes = 1; rn.unsolved = 0;
+            Node& cn = s.nodes[child];
+            cn.type = T_LOSS; cn.valueSum = -1.0f; cn.endInPly = 0;
+            rn.visits = 1;
+            rn.type = T_WIN; rn.valueSum = 1.0f * (float)(rn.visits + 1); rn.endInPly = 1;
+            s.nodes[root] = rn;
+            gm.root = root;
+            gm.status = ST_DONE;
+            return;
+        }
+    }
+    const int root = node_alloc(s, team, 0);
+    s.nodes[root].hash = rootHash;
+    gm.root = root;
+    if (prm.enableTranspositions) tt_insert_or_get(s, rootHash, root);
+    gm.status = ST_SEARCHING;
+}
+
+// root_edge_stats / root_q (agent.cc:1004-1024): out[g][0] = edge count, then per edge (moveA, moveB, visits).
+struct RootOut { int* counts; u32* moveA; u32* moveB; int* visits; float* q; float* prior; float* rootQ; int* info; int maxEdges; };
+__global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut o) {
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    Game& gm = *s.g;
+    int n = 0;
+    float rq = 0.0f;
+    if (gm.root >= 0) {
+        const Node& r = s.nodes[gm.root];
+        rq = r.type == T_WIN ? 1.0f : r.type == T_LOSS ? -1.0f : r.type == T_DRAW ? 0.0f : (r.visits > 0 ? r.valueSum / (float)r.visits : r.valueSum);
+        if (r.flags & F_EXPANDED) {
+            n = r.expanded < o.maxEdges ? r.expanded : o.maxEdges;
+            const Edge* e = edges_of(s, r);
+            for (int i = lane; i < n; i += 64) {
+                const size_t k = (size_t)g * o.maxEdges + i;
+                o.moveA[k] = e[i].moveA; o.moveB[k] = e[i].moveB; o.visits[k] = e[i].visits; o.q[k] = e[i].q; o.prior[k] = e[i].prior;
+            }
+        }
+    }
+    if (lane == 0) {
+        o.counts[g] = n; o.rootQ[g] = rq;
+        int* inf = o.info + (size_t)g * 12;
+        inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
+        inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
+        inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = (int)gm.arenaTop; inf[11] = gm.ttCount;
+    }
+}
+
+// Board::push_move of the chosen joint action + team / time-advantage flip (selfplay.cc:694-716)
+__global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* moveA, const u32* moveB, const uint8_t* mask) {
+    __shared__ RulesTab s_rt;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x;
+    if (mask && !mask[g]) return;
+    G s = make_view(pl, prm, g);
+    Path p;
+    path_reset(s, p);
+    const u32 ma = moveA[g], mb = moveB[g];
+    if (p.jb.hlen[0] + 2 >= HIST_GAME || p.jb.hlen[1] + 2 >= HIST_GAME) { s.g->overflow |= 8; return; }
+    jb_make(s_rt, p.jb, ma, mb, true);
+    store_pos(&s.g->pos[0], p.jb.bd[0]);
+    store_pos(&s.g->pos[1], p.jb.bd[1]);
+    if (ma) s.g->lastMove[0] = ma;
+    if (mb) s.g->lastMove[1] = mb;
+    s.g->hlen[0] = p.jb.hlen[0]; s.g->hlen[1] = p.jb.hlen[1];
+    s.g->prefix[0] = p.jb.prefix[0]; s.g->prefix[1] = p.jb.prefix[1];
+    s.g->team ^= 1; s.g->adv ^= 1;
+}
+
+// (re)start games from a compact board (history restarts, like Board::set)
+__global__ __launch_bounds__(64) void k_set_games(Pools pl, Params prm, const hm_board* boards, const uint8_t* mask) {
+    __shared__ RulesTab s_rt;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x;
+    if (mask && !mask[g]) return;
+    G s = make_view(pl, prm, g);
+    Game& gm = *s.g;
+    gm.pos[0] = boards[g].pos[0]; gm.pos[1] = boards[g].pos[1];
+    gm.lastMove[0] = gm.lastMove[1] = 0;            // Board::set clears moveHistory (board.cc:38,48)
+    gm.team = boards[g].team; gm.adv = boards[g].time_adv;
+    for (int b = 0; b < 2; ++b) {
+        P q;
+        load_pos(q, &gm.pos[b]);
+        const u64 k = rep_key(s_rt, q);
+        s.hist[b][0] = k;
+        gm.hlen[b] = 1;
+        gm.prefix[b] = mix_hash(HISTORY_HASH_SEED, k);
+    }
+    gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0;
+}
+
+// game state export: hm_board (for record planes / host bookkeeping) + terminal flags
+// flags[g]: bit0 is_checkmate(team, adv), bit1 is_draw()  (selfplay.cc:608-616)
+__global__ __launch_bounds__(64) void k_game_state(Pools pl, Params prm, hm_board* out, int* flags) {
+    __shared__ RulesTab s_rt;
+    __shared__ u32 scratch[2 * HM_MAX_MOVES];
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    Path p;
+    path_reset(s, p);
+    const bool mate = is_checkmate(s_rt, p.jb.bd, s.g->team, s.g->adv != 0, scratch);
+    const bool draw = jb_is_draw(p.jb, 0);
+    if (lane == 0) {
+        hm_board hb;
+        hb.pos[0] = s.g->pos[0]; hb.pos[1] = s.g->pos[1];
+        hb.last_move[0] = s.g->lastMove[0]; hb.last_move[1] = s.g->lastMove[1];
+        for (int b = 0; b < 2; ++b) { int rc = repetition_count(hist_of(p.jb, b)); hb.rep_count[b] = (uint8_t)(rc > 3 ? 3 : rc); }
+        hb.team = (uint8_t)s.g->team; hb.time_adv = (uint8_t)s.g->adv; hb.reserved = 0;
+        out[g] = hb;
+        flags[g] = (mate ? 1 : 0) | (draw ? 2 : 0);
+    }
+}
+
+// Raw-policy opening support (selfplay.cc:277-376): per game, actions (+pass) and probabilities of
+// both boards from the net's policy heads; plus action_leads_to_terminal for a proposed action.
+struct RawOut { u32* moves; float* probs; int* counts; uint8_t* caps; uint8_t* onTurn; };   // [g][2][HM_MAX_MOVES]
+__global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const uint16_t* piA, const uint16_t* piB, RawOut o) {
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    // reuse expand_leaf's prior computation through a throw-away context: replicate its first half
+    P bd[2];
+    load_pos(bd[0], &s.g->pos[0]);
+    load_pos(bd[1], &s.g->pos[1]);
+    const int team = s.g->team;
+    const bool on[2] = {(int)bd[0].stm == team, (int)bd[1].stm == (team ^ 1)};
+    for (int b = 0; b < 2; ++b) {
+        u32* list = L.lists[b];
+        float* pr = L.priors[b];
+        int n = 0;
+        if (on[b]) {
+            n = gen_legal(s_rt.att, bd[b], list);
+            int k = 0;
+            for (int i = 0; i < n; ++i) {
+                const u32 m = list[i];
+                const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
+                if (!bad) list[k++] = m;
+            }
+            n = k;
+        }
+        list[n] = 0;
+        const uint16_t* pol = (b == 0 ? piA : piB) + (size_t)g * HM_POLICY_VALUES;
+        const int stm = (int)bd[b].stm;
+        if (n == 0) pr[0] = 1.0f;
+        else {
+            float mx = -INFINITY;
+            for (int i = 0; i < n + 1; ++i) {
+                const u32 m = list[i];
+                int idx;
+                if (m == 0) idx = 0;
+                else if ((m & (15u << 12)) == HM_MT_DROP) idx = pl.polDrop[(stm * 64 + (m & 63)) * 8 + ((m >> 16) & 63)];
+                else {
+                    const int knight = ((m & (15u << 12)) == HM_MT_PROMOTION && ((m >> 16) & 63) == HM_KNIGHT) ? 1 : 0;
+                    idx = pl.polNormal[((stm * 64 + ((m >> 6) & 63)) * 64 + (m & 63)) * 2 + knight];
+                }
+                const float lg = idx >= 0 ? h2f(pol[idx]) : -INFINITY;
+                pr[i] = lg;
+                if (finite_f(lg)) mx = fmaxf(mx, lg);
+            }
+            if (!finite_f(mx)) { for (int i = 0; i < n + 1; ++i) pr[i] = 1.0f / (float)(n + 1); }
+            else {
+                double sum = 0.0;
+                for (int i = 0; i < n + 1; ++i) { const float lg = pr[i]; pr[i] = finite_f(lg) ? hm_expf(lg - mx) : 0.0f; sum += (double)pr[i]; }
+                for (int i = 0; i < n + 1; ++i) pr[i] = (float)((double)pr[i] / sum);
+            }
+        }
+        const size_t base = ((size_t)g * 2 + b) * HM_MAX_MOVES;
+        for (int i = lane; i < n + 1; i += 64) {
+            o.moves[base + i] = list[i]; o.probs[base + i] = pr[i];
+            o.caps[base + i] = (list[i] != 0 && is_capture(bd[b], list[i])) ? 1 : 0;
+        }
+        if (lane == 0) { o.counts[g * 2 + b] = n + 1; o.onTurn[g * 2 + b] = on[b]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// action_leads_to_terminal (selfplay.cc:378-390)
+__global__ __launch_bounds__(64) void k_action_terminal(Pools pl, Params prm, const u32* moveA, const u32* moveB, int* out) {
+    __shared__ RulesTab s_rt;
+    __shared__ u32 scratch[2 * HM_MAX_MOVES];
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    Path p;
+    path_reset(s, p);
+    const int team = s.g->team;
+    const bool adv = s.g->adv != 0;
+    // the future position's keys go just past the game history (scratch region of the pool)
+    jb_make(s_rt, p.jb, moveA[g], moveB[g], true);
+    wave_fence();
+    const bool t = is_checkmate(s_rt, p.jb.bd, team ^ 1, !adv, scratch) || is_checkmate(s_rt, p.jb.bd, team, adv, scratch) || jb_is_draw(p.jb, 0);
+    if (lane == 0) out[g] = t ? 1 : 0;
+}
+
+// test hook: Board queries on compact boards without history (tests/test_gpu_rules.py)
+__global__ __launch_bounds__(64) void k_rules_probe(const RulesTab* rules, const hm_board* boards, int n, int* out /*n*8*/, u64* keys /*n*4*/) {
+    __shared__ RulesTab s_rt;
+    __shared__ u32 scratch[6 * HM_MAX_MOVES];
+    __shared__ u64 hk[2][4];
+    stage_table(&s_rt, rules);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        JBoard j;
+        load_pos(j.bd[0], &boards[i].pos[0]);
+        load_pos(j.bd[1], &boards[i].pos[1]);
+        for (int b = 0; b < 2; ++b) {
+            const u64 k = rep_key(s_rt, j.bd[b]);
+            hk[b][0] = k;
+            j.hist[b] = hk[b]; j.hlen[b] = 1; j.prefix[b] = mix_hash(HISTORY_HASH_SEED, k);
+        }
+        __builtin_amdgcn_wave_barrier();
+        int r[8];
+        r[0] = is_checkmate(s_rt, j.bd, 0, false, scratch);
+        r[1] = is_checkmate(s_rt, j.bd, 0, true, scratch);
+        r[2] = is_checkmate(s_rt, j.bd, 1, false, scratch);
+        r[3] = is_checkmate(s_rt, j.bd, 1, true, scratch);
+        r[4] = checkers_of(s_rt.att, j.bd[0]) != 0;
+        r[5] = checkers_of(s_rt.att, j.bd[1]) != 0;
+        int e0 = 0, e1 = 0;
+        r[6] = classify_terminal_position(s_rt, j, boards[i].team, boards[i].team, boards[i].time_adv != 0, 1, &e0, scratch) | (e0 << 8);
+        r[7] = classify_terminal_position(s_rt, j, boards[i].team ^ 1, boards[i].team, boards[i].time_adv != 0, 1, &e1, scratch) | (e1 << 8);
+        if (lane == 0) {
+            for (int q = 0; q < 8; ++q) out[(size_t)i * 8 + q] = r[q];
+            keys[(size_t)i * 4 + 0] = board_hash_key(j.bd[0], j.bd[1], hist_of(j, 0), hist_of(j, 1), false, s_rt.zob.time_adv);
+            keys[(size_t)i * 4 + 1] = board_hash_key(j.bd[0], j.bd[1], hist_of(j, 0), hist_of(j, 1), true, s_rt.zob.time_adv);
+            keys[(size_t)i * 4 + 2] = hk[0][0];
+            keys[(size_t)i * 4 + 3] = hk[1][0];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace hms
+
+// =========================================================================================
+// host side
+// =========================================================================================
+using namespace hms;
+
+struct hm_sp {
+    Params prm;
+    Pools pl;
+    int nGames;
+    int maxEdges;
+    std::vector<void*> allocs;
+    // device outputs
+    RootOut ro;
+    u64* d_rootHash;
+    int* d_active;
+    int* d_target;
+    u64* d_seed;
+    uint8_t* d_mask;
+    u32 *d_moveA, *d_moveB;
+    hm_board* d_boards;
+    int* d_flags;
+    RawOut raw;
+    int* d_term;
+    float alpha = 0.0f, eps = 0.0f;
+    std::vector<u64> h_rootHash;
+};
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+static int dalloc(hm_sp* sp, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 8));
+    if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    (void)hipMemset(q, 0, std::max<size_t>(count * sizeof(T), 8));
+    sp->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return 0;
+}
+
+static RulesTab* g_rules_dev = nullptr;
+static int* g_polN_dev = nullptr;
+static int* g_polD_dev = nullptr;
+static float* g_cpuct_dev = nullptr;
+static int *g_pwRoot_dev = nullptr, *g_pwNode_dev = nullptr;
+
+static int ensure_search_tables() {
+    if (g_rules_dev) return 0;
+    const HostTables& h = hm_host_tables();
+    if (!h.built) return hm_fail(HM_ERR_STATE, "hm_init() has not been called");
+    static RulesTab rt;
+    rt.att = h.dev.att; rt.zob = h.dev.zob; rt.in_hand_const = h.in_hand_const;
+    // promoted-piece marks of the repetition key: splitmix64 stream (same constants as the oracle)
+    uint64_t x = 0x9e3779b97f4a7c15ULL;
+    for (int s = 0; s < 64; ++s) {
+        x += 0x9e3779b97f4a7c15ULL;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        rt.z_promoted[s] = z ^ (z >> 31);
+    }
+    for (int k = 0; k < 64; ++k) {
+        rt.pocket_f16[k] = (uint16_t)h.plane_consts.pocket[HM_DT_F16][k];
+        rt.r50_f16[k] = (uint16_t)h.plane_consts.r50[HM_DT_F16][k];
+    }
+    HIPCHK(hipMalloc(&g_rules_dev, sizeof(RulesTab)));
+    HIPCHK(hipMemcpy(g_rules_dev, &rt, sizeof rt, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&g_polN_dev, sizeof(h.dev.pol_normal)));
+    HIPCHK(hipMemcpy(g_polN_dev, h.dev.pol_normal, sizeof(h.dev.pol_normal), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&g_polD_dev, sizeof(h.dev.pol_drop)));
+    HIPCHK(hipMemcpy(g_polD_dev, h.dev.pol_drop, sizeof(h.dev.pol_drop), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp** out) {
+    if (!out || n_games <= 0 || max_nodes <= 0) return hm_fail(HM_ERR_INVALID, "bad hm_sp_create arguments");
+    if (int rc = ensure_search_tables()) return rc;
+    hm_search_config c;
+    if (cfg) c = *cfg; else hm_search_config_default(&c);
+    hm_sp* sp = new hm_sp();
+    sp->nGames = n_games;
+    sp->maxEdges = 256;
+    Params& p = sp->prm;
+    p.nGames = n_games;
+    p.nodeCap = 3 * (max_nodes + 2 * BATCH) + 64;
+    int tt = 64;
+    while (tt < 4 * p.nodeCap) tt <<= 1;
+    p.ttCap = tt;
+    p.arenaCap = (u32)std::min<size_t>(((size_t)(max_nodes + 2 * BATCH) * 6144 + (1 << 16)) / 8, (size_t)1 << 28);
+    p.cpuctInit = c.cpuct_init; p.cpuctBase = c.cpuct_base; p.fpuReduction = c.fpu_reduction; p.drawContempt = c.draw_contempt;
+    p.wdlWeight = c.wdl_value_weight; p.mlDiscount = c.moves_left_discount;
+    p.enableTranspositions = c.enable_transpositions; p.enableDynamicFpu = c.enable_dynamic_fpu; p.enableWdl = c.enable_wdl_eval;
+    Pools& pl = sp->pl;
+    const size_t G_ = (size_t)n_games;
+    int rc = 0;
+    rc |= dalloc(sp, &pl.games, G_);
+    rc |= dalloc(sp, &pl.nodes, G_ * p.nodeCap);
+    rc |= dalloc(sp, &pl.arena, G_ * p.arenaCap);
+    rc |= dalloc(sp, &pl.ttKeys, G_ * p.ttCap);
+    rc |= dalloc(sp, &pl.ttVals, G_ * p.ttCap);
+    rc |= dalloc(sp, &pl.ctx, G_ * 2 * BATCH);
+    rc |= dalloc(sp, &pl.traj, G_ * 2 * BATCH * MAX_TRAJ);
+    rc |= dalloc(sp, &pl.hist, G_ * 2 * HIST_CAP);
+    rc |= dalloc(sp, &pl.noise, G_ * 2 * NOISE_CAP);
+    if (rc) { hm_sp_destroy(sp); return rc; }
+    // cpuct(N) and the PW schedule from the reference's own float expressions (search_params.h:307-317)
+    std::vector<float> cp(MAX_VISITS_TAB);
+    std::vector<int> pr(MAX_VISITS_TAB), pn(MAX_VISITS_TAB);
+    for (int v = 0; v < MAX_VISITS_TAB; ++v) {
+        cp[v] = std::log(((float)v + c.cpuct_base + 1.0f) / c.cpuct_base) + c.cpuct_init;
+        auto allowed = [&](float coef) { return v <= 0 ? 1 : (int)std::ceil(coef * std::pow((float)v, c.pw_exponent)); };
+        pr[v] = allowed(c.root_pw_coefficient);
+        pn[v] = allowed(c.pw_coefficient);
+    }
+    float* dcp; int *dpr, *dpn;
+    rc |= dalloc(sp, &dcp, MAX_VISITS_TAB); rc |= dalloc(sp, &dpr, MAX_VISITS_TAB); rc |= dalloc(sp, &dpn, MAX_VISITS_TAB);
+    if (rc) { hm_sp_destroy(sp); return rc; }
+    (void)hipMemcpy(dcp, cp.data(), sizeof(float) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpr, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpn, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    pl.cpuctTab = dcp; pl.pwRoot = dpr; pl.pwNode = dpn;
+    pl.rules = g_rules_dev; pl.polNormal = g_polN_dev; pl.polDrop = g_polD_dev;
+    RootOut& ro = sp->ro;
+    ro.maxEdges = sp->maxEdges;
+    rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
+    rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
+    rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * 12);
+    rc |= dalloc(sp, &sp->d_rootHash, G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_target, G_);
+    rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
+    rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
+    rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
+    rc |= dalloc(sp, &sp->raw.caps, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.counts, G_ * 2); rc |= dalloc(sp, &sp->raw.onTurn, G_ * 2);
+    if (rc) { hm_sp_destroy(sp); return rc; }
+    sp->h_rootHash.resize(G_);
+    *out = sp;
+    return 0;
+}
+
+int hm_sp_destroy(hm_sp* sp) {
+    if (!sp) return 0;
+    for (void* p : sp->allocs) (void)hipFree(p);
+    delete sp;
+    return 0;
+}
+
+int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask) {
+    if (!sp || !boards) return hm_fail(HM_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpy(sp->d_boards, boards, sizeof(hm_board) * sp->nGames, hipMemcpyHostToDevice));
+    if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, sp->nGames, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_games, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_boards, mask ? sp->d_mask : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+// Dirichlet gamma draws exactly as node.h:286-315 (std::gamma_distribution<float> on std::mt19937_64
+// seeded rootNoiseSeed ^ positionHash ^ salt); the device mixes them into the root priors.
+static void fill_noise(hm_sp* sp, const uint64_t* seeds, float alpha, std::vector<float>& buf) {
+    buf.assign((size_t)sp->nGames * 2 * NOISE_CAP, 0.0f);
+    static const uint64_t salts[2] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL};
+    for (int g = 0; g < sp->nGames; ++g)
+        for (int b = 0; b < 2; ++b) {
+            std::mt19937_64 eng(seeds[g] ^ sp->h_rootHash[g] ^ salts[b]);
+            std::gamma_distribution<float> gamma(alpha, 1.0f);
+            float* dst = buf.data() + ((size_t)g * 2 + b) * NOISE_CAP;
+            for (int i = 0; i < NOISE_CAP; ++i) dst[i] = gamma(eng);
+        }
+}
+
+int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask) {
+    if (!sp || !target_nodes) return hm_fail(HM_ERR_INVALID, "null argument");
+    const int G_ = sp->nGames;
+    HIPCHK(hipMemcpy(sp->d_target, target_nodes, sizeof(int) * G_, hipMemcpyHostToDevice));
+    std::vector<uint64_t> seeds(G_, 0);
+    if (noise_seeds) seeds.assign(noise_seeds, noise_seeds + G_);
+    HIPCHK(hipMemcpy(sp->d_seed, seeds.data(), 8 * (size_t)G_, hipMemcpyHostToDevice));
+    if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_begin, dim3(G_), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, alpha, eps, mask ? sp->d_mask : nullptr, sp->d_rootHash);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(sp->h_rootHash.data(), sp->d_rootHash, 8 * (size_t)G_, hipMemcpyDeviceToHost));
+    if (alpha > 0.0f && eps > 0.0f) {
+        std::vector<float> nz;
+        fill_noise(sp, seeds.data(), alpha, nz);
+        HIPCHK(hipMemcpy(sp->pl.noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    sp->alpha = alpha; sp->eps = eps;
+    return 0;
+}
+
+int hm_sp_collect(hm_sp* sp, void* d_planes_cur, void* d_planes_next, void* stream) {
+    if (!sp || !d_planes_cur || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
+    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+                       static_cast<uint16_t*>(d_planes_cur), static_cast<uint16_t*>(d_planes_next));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
+                  int* active_games, void* stream) {
+    if (!sp || !d_value || !d_pi_a || !d_pi_b || !d_wdl || !d_moves_left) return hm_fail(HM_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipMemsetAsync(sp->d_active, 0, sizeof(int), st));
+    NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
+             static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
+    hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64), 0, st, sp->pl, sp->prm, o, sp->d_active);
+    HIPCHK(hipGetLastError());
+    if (active_games) {
+        HIPCHK(hipMemcpyAsync(active_games, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior, float* root_q, int* info, int max_edges) {
+    if (!sp || !counts) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (max_edges != sp->maxEdges) return hm_fail(HM_ERR_INVALID, "max_edges must equal hm_sp_max_edges()");
+    const size_t G_ = sp->nGames, E = (size_t)sp->maxEdges;
+    hipLaunchKernelGGL(k_root_stats, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->ro);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(counts, sp->ro.counts, 4 * G_, hipMemcpyDeviceToHost));
+    if (move_a) HIPCHK(hipMemcpy(move_a, sp->ro.moveA, 4 * G_ * E, hipMemcpyDeviceToHost));
+    if (move_b) HIPCHK(hipMemcpy(move_b, sp->ro.moveB, 4 * G_ * E, hipMemcpyDeviceToHost));
+    if (visits) HIPCHK(hipMemcpy(visits, sp->ro.visits, 4 * G_ * E, hipMemcpyDeviceToHost));
+    if (q) HIPCHK(hipMemcpy(q, sp->ro.q, 4 * G_ * E, hipMemcpyDeviceToHost));
+    if (prior) HIPCHK(hipMemcpy(prior, sp->ro.prior, 4 * G_ * E, hipMemcpyDeviceToHost));
+    if (root_q) HIPCHK(hipMemcpy(root_q, sp->ro.rootQ, 4 * G_, hipMemcpyDeviceToHost));
+    if (info) HIPCHK(hipMemcpy(info, sp->ro.info, 4 * G_ * 12, hipMemcpyDeviceToHost));
+    return 0;
+}
+int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+
+int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
+    if (!sp || !move_a || !move_b) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    HIPCHK(hipMemcpy(sp->d_moveA, move_a, 4 * G_, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp->d_moveB, move_b, 4 * G_, hipMemcpyHostToDevice));
+    if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    hipLaunchKernelGGL(k_game_state, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_boards, sp->d_flags);
+    HIPCHK(hipGetLastError());
+    if (boards) HIPCHK(hipMemcpy(boards, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToHost));
+    if (flags) HIPCHK(hipMemcpy(flags, sp->d_flags, 4 * G_, hipMemcpyDeviceToHost));
+    if (d_boards_out) HIPCHK(hipMemcpy(d_boards_out, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps, int* counts, uint8_t* on_turn) {
+    if (!sp || !d_pi_a || !d_pi_b || !moves || !probs || !counts) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    hipLaunchKernelGGL(k_raw_policy, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, static_cast<const uint16_t*>(d_pi_a),
+                       static_cast<const uint16_t*>(d_pi_b), sp->raw);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(moves, sp->raw.moves, 4 * G_ * 2 * HM_MAX_MOVES, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(probs, sp->raw.probs, 4 * G_ * 2 * HM_MAX_MOVES, hipMemcpyDeviceToHost));
+    if (caps) HIPCHK(hipMemcpy(caps, sp->raw.caps, G_ * 2 * HM_MAX_MOVES, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, sp->raw.counts, 4 * G_ * 2, hipMemcpyDeviceToHost));
+    if (on_turn) HIPCHK(hipMemcpy(on_turn, sp->raw.onTurn, G_ * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, int* out) {
+    if (!sp || !move_a || !move_b || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    HIPCHK(hipMemcpy(sp->d_moveA, move_a, 4 * G_, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(sp->d_moveB, move_b, 4 * G_, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_action_terminal, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, sp->d_term);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, sp->d_term, 4 * G_, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys) {
+    if (int rc = ensure_search_tables()) return rc;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_rules_probe, dim3((unsigned)std::min<size_t>(n, 4096)), dim3(64), 0, 0, g_rules_dev, d_boards, (int)n, d_out, d_keys);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+}  // extern "C"

@@ -144,6 +144,74 @@ int hm_make_moves(const hm_board* d_boards, const hm_move* d_move_a, const hm_mo
 /* ------------------------------------------------------------------ */
 int hm_perft(const hm_board* root, int depth, int shard, int nshards, uint64_t* nodes, double* seconds);
 
+/* ================================================================== */
+/* GPU-resident self-play search engine (rollout seam).                */
+/*                                                                      */
+/* Replaces Agent::run_search + SearchThread + Node + TranspositionTable*/
+/* (search/agent.h:136-144, search/searchthread.cc:255-916) for G       */
+/* concurrent games, and the evaluator seam of class Engine             */
+/* (nn/engine.h:43-81) as a pair of device tensors: the engine WRITES   */
+/* fp16 planes [G*8, 74, 8, 8] (collect) and READS fp16 heads (process):*/
+/* value [G*8], pi_a / pi_b [G*8, 4672] raw logits plane-major, wdl     */
+/* [G*8, 3] ordered loss,draw,win, moves_left [G*8]                     */
+/* (searchthread.cc:474-484, 576-578, 609-617).  Row g*8+k belongs to   */
+/* game g; unused rows are ignored.  One lockstep iteration =           */
+/* hm_sp_collect -> net(planes_cur) -> hm_sp_process, then the caller   */
+/* swaps planes_cur / planes_next (the reference's double-buffered      */
+/* lookahead, searchthread.cc:661-708).                                 */
+/* ================================================================== */
+typedef struct hm_sp hm_sp;
+
+/* search/search_params.h:26-295 (RuntimeConfig + constants) */
+typedef struct hm_search_config {
+    float cpuct_init, cpuct_base;          /* 2.5, 19652 */
+    float fpu_reduction;                   /* 1.0 */
+    float draw_contempt;                   /* 0.0 */
+    float wdl_value_weight;                /* 0.25 */
+    float moves_left_discount;             /* 0.005 */
+    float pw_coefficient, root_pw_coefficient, pw_exponent;   /* 2, 4, 0.4 */
+    int   enable_transpositions;           /* 1 */
+    int   enable_dynamic_fpu;              /* 1 */
+    int   enable_wdl_eval;                 /* 1 */
+} hm_search_config;
+void hm_search_config_default(hm_search_config* cfg);
+
+/* n_games game slots, trees sized for searches of up to max_nodes nodes. */
+int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp** out);
+int hm_sp_destroy(hm_sp* sp);
+/* (Re)start games from host boards[n_games] (Board::set, board.cc:27-49: history restarts);
+ * team / time_adv of each hm_board give the side to act.  mask[g]==0 leaves game g alone. */
+int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask);
+/* Agent::run_search prologue for every (masked) game: early outs, 1-ply root mate scan, root +
+ * TT setup (agent.cc:421-558).  Dirichlet noise (alpha, eps, per-game rootNoiseSeed) as
+ * node.h:286-315; alpha == 0 disables it. */
+int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask);
+int hm_sp_collect(hm_sp* sp, void* d_planes_cur, void* d_planes_next, void* stream);
+/* active_games (host, optional): number of games still searching after this step (forces a sync). */
+int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl,
+                  const void* d_moves_left, int* active_games, void* stream);
+/* Agent::root_edge_stats / root_q (agent.cc:1004-1024) for all games -> host arrays
+ * [n_games][max_edges]; info[g][12] = status, nodes, eval rows, same-batch collisions,
+ * reservation collisions, node count, root type, root visits, overflow flags, max depth,
+ * arena words, TT entries. */
+int hm_sp_max_edges(const hm_sp* sp);
+int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
+                     float* root_q, int* info, int max_edges);
+/* Board::push_move of the chosen joint action, then team / time-advantage flip (selfplay.cc:694-716). */
+int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask);
+/* Current boards (+ rep counts, last moves) and flags: bit0 is_checkmate(team, adv), bit1 is_draw()
+ * (selfplay.cc:608-616).  d_boards_out (device, optional) receives the same hm_board array. */
+int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out);
+/* Raw-policy opening (selfplay.cc:277-300): per game and board the action list (+pass last) and
+ * masked-softmax probabilities from policy heads [n_games, 4672] (one row per game). */
+int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps,
+                     int* counts, uint8_t* on_turn);
+/* action_leads_to_terminal (selfplay.cc:378-390). */
+int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, int* out);
+/* Test hook: Board::is_checkmate x4, in-check x2, classify_terminal_position x2 and hash keys for
+ * history-free boards (d_out: n*8 ints, d_keys: n*4 u64: hash_key(adv=0), hash_key(adv=1), repetition keys). */
+int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,65 @@ size_t ora_random_positions(uint64_t seed, size_t n, int maxPlies, hm_board* out
     return produced;
 }
 
+// ---- search (oracle/search.hpp) ------------------------------------------------------------
+typedef void (*ora_eval_cb)(const uint16_t* planes, int n, uint16_t* value, uint16_t* piA, uint16_t* piB,
+                            uint16_t* wdl, uint16_t* ml);
+void* ora_search_new(int tie_mode, int exp_mode) {
+    Search* s = new Search();
+    s->cfg.tie_mode = tie_mode; s->cfg.exp_mode = exp_mode;
+    s->evaluator = hash_evaluator;
+    return s;
+}
+void ora_search_free(void* s) { delete static_cast<Search*>(s); }
+void ora_search_set_callback(void* sp, ora_eval_cb cb) {
+    Search* s = static_cast<Search*>(sp);
+    if (!cb) { s->evaluator = hash_evaluator; return; }
+    s->evaluator = [cb](const uint16_t* planes, int n, EvalOutputs& out) {
+        out.value.assign(n, 0); out.piA.assign((size_t)n * HM_POLICY_VALUES, 0); out.piB.assign((size_t)n * HM_POLICY_VALUES, 0);
+        out.wdl.assign((size_t)n * 3, 0); out.movesLeft.assign(n, 0);
+        cb(planes, n, out.value.data(), out.piA.data(), out.piB.data(), out.wdl.data(), out.movesLeft.data());
+    };
+}
+void ora_search_set_noise(void* sp, float alpha, float eps, uint64_t seed) {
+    Search* s = static_cast<Search*>(sp);
+    s->cfg.rootDirichletAlpha = alpha; s->cfg.rootDirichletEpsilon = eps; s->cfg.rootNoiseSeed = seed;
+}
+void ora_search_set_transpositions(void* sp, int on) { static_cast<Search*>(sp)->cfg.enableTranspositions = on != 0; }
+int ora_search_run(void* sp, void* board, int team, int adv, int targetNodes) {
+    Search* s = static_cast<Search*>(sp);
+    s->evalTrace.clear(); s->sameBatchCollisions = s->reservationCollisions = s->evalCalls = s->evalRows = 0;
+    return s->run(*static_cast<Board*>(board), team, adv != 0, targetNodes) ? 1 : 0;
+}
+int ora_search_edges(void* sp, uint32_t* moveA, uint32_t* moveB, int* visits, float* q, float* prior, int cap) {
+    auto e = static_cast<Search*>(sp)->root_edge_stats();
+    int n = (int)std::min<size_t>(e.size(), (size_t)cap);
+    for (int i = 0; i < n; ++i) { moveA[i] = e[i].moveA; moveB[i] = e[i].moveB; visits[i] = e[i].visits; q[i] = e[i].q; prior[i] = e[i].prior; }
+    return (int)e.size();
+}
+float ora_search_root_q(void* sp) { return static_cast<Search*>(sp)->root_q(); }
+void ora_search_info(void* sp, int* out /*8*/) {
+    Search* s = static_cast<Search*>(sp);
+    out[0] = s->nodesSearched; out[1] = s->evalRows; out[2] = s->evalCalls; out[3] = s->sameBatchCollisions;
+    out[4] = s->reservationCollisions; out[5] = s->nodeCounter; out[6] = s->root ? (int)s->root->nodeType : -1;
+    out[7] = s->root ? s->root->visits : 0;
+}
+int ora_search_trace(void* sp, uint64_t* out, int cap) {
+    Search* s = static_cast<Search*>(sp);
+    int n = (int)std::min<size_t>(s->evalTrace.size(), (size_t)cap);
+    for (int i = 0; i < n; ++i) out[i] = s->evalTrace[i];
+    return (int)s->evalTrace.size();
+}
+void ora_hash_evaluator(const uint16_t* planes, int n, uint16_t* value, uint16_t* piA, uint16_t* piB, uint16_t* wdl, uint16_t* ml) {
+    EvalOutputs o;
+    hash_evaluator(planes, n, o);
+    std::memcpy(value, o.value.data(), 2 * (size_t)n); std::memcpy(piA, o.piA.data(), 2 * o.piA.size());
+    std::memcpy(piB, o.piB.data(), 2 * o.piB.size()); std::memcpy(wdl, o.wdl.data(), 2 * o.wdl.size());
+    std::memcpy(ml, o.movesLeft.data(), 2 * (size_t)n);
+}
+int ora_pw_allowed_children(int visits, int isRoot) { return get_allowed_children(visits, isRoot ? 4.0f : 2.0f, 0.4f); }
+float ora_get_cpuct(float v) { return get_cpuct(v, 2.5f, 19652.0f); }
+float ora_portable_expf(float x) { return portable_expf(x); }
+
 // timing helpers for bench.py's cpu_baseline leg
 double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, int reps) {
     auto t0 = std::chrono::steady_clock::now();

@@ -164,3 +164,74 @@ def policy_tables(impl="ora"):
     drop = np.zeros((2, 64, 8), dtype=np.int32)
     (lib.ora_policy_tables if impl == "ora" else ref.ref_policy_tables)(normal.ctypes.data, drop.ctypes.data)
     return normal, drop
+
+
+# ---- search oracle (oracle/search.hpp) -------------------------------------------------------
+lib.ora_search_new.restype, lib.ora_search_new.argtypes = _vp, [_i, _i]
+lib.ora_search_free.restype, lib.ora_search_free.argtypes = None, [_vp]
+lib.ora_search_set_noise.restype, lib.ora_search_set_noise.argtypes = None, [_vp, C.c_float, C.c_float, _u64]
+lib.ora_search_set_transpositions.restype, lib.ora_search_set_transpositions.argtypes = None, [_vp, _i]
+lib.ora_search_run.restype, lib.ora_search_run.argtypes = _i, [_vp, _vp, _i, _i, _i]
+lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]
+lib.ora_search_root_q.restype, lib.ora_search_root_q.argtypes = C.c_float, [_vp]
+lib.ora_search_info.restype, lib.ora_search_info.argtypes = None, [_vp, _vp]
+lib.ora_search_trace.restype, lib.ora_search_trace.argtypes = _i, [_vp, _vp, _i]
+lib.ora_hash_evaluator.restype, lib.ora_hash_evaluator.argtypes = None, [_vp, _i, _vp, _vp, _vp, _vp, _vp]
+lib.ora_pw_allowed_children.restype, lib.ora_pw_allowed_children.argtypes = _i, [_i, _i]
+lib.ora_get_cpuct.restype, lib.ora_get_cpuct.argtypes = C.c_float, [C.c_float]
+lib.ora_portable_expf.restype, lib.ora_portable_expf.argtypes = C.c_float, [C.c_float]
+EVAL_CB = C.CFUNCTYPE(None, _vp, _i, _vp, _vp, _vp, _vp, _vp)
+lib.ora_search_set_callback.restype, lib.ora_search_set_callback.argtypes = None, [_vp, EVAL_CB]
+
+
+class Search:
+    """Single-thread reference-schedule search (tie_mode/exp_mode: see oracle/search.hpp)."""
+
+    def __init__(self, tie_mode=1, exp_mode=1):
+        self.h = lib.ora_search_new(tie_mode, exp_mode)
+        self._cb = None
+
+    def __del__(self):
+        try:
+            lib.ora_search_free(self.h)
+        except Exception:
+            pass
+
+    def set_noise(self, alpha, eps, seed): lib.ora_search_set_noise(self.h, alpha, eps, seed)
+
+    def set_evaluator(self, fn):
+        """fn(planes uint16 [n,4736]) -> (value[n], piA[n,4672], piB[n,4672], wdl[n,3], ml[n]) uint16 arrays."""
+        def cb(planes, n, value, pia, pib, wdl, ml):
+            pl = np.ctypeslib.as_array(C.cast(planes, C.POINTER(C.c_uint16)), shape=(n, 4736))
+            v, a, b, w, m = fn(pl)
+            for dst, src, cnt in ((value, v, n), (pia, a, n * 4672), (pib, b, n * 4672), (wdl, w, n * 3), (ml, m, n)):
+                C.memmove(dst, np.ascontiguousarray(src, dtype=np.uint16).ctypes.data, 2 * cnt)
+        self._cb = EVAL_CB(cb)
+        lib.ora_search_set_callback(self.h, self._cb)
+
+    def run(self, board, team, adv, nodes):
+        return bool(lib.ora_search_run(self.h, board.h, team, int(adv), nodes))
+
+    def edges(self):
+        cap = 1024
+        ma = np.zeros(cap, np.uint32); mb = np.zeros(cap, np.uint32); v = np.zeros(cap, np.int32)
+        q = np.zeros(cap, np.float32); p = np.zeros(cap, np.float32)
+        n = lib.ora_search_edges(self.h, ma.ctypes.data, mb.ctypes.data, v.ctypes.data, q.ctypes.data, p.ctypes.data, cap)
+        return dict(move_a=ma[:n], move_b=mb[:n], visits=v[:n], q=q[:n], prior=p[:n])
+
+    def info(self):
+        o = np.zeros(8, np.int32)
+        lib.ora_search_info(self.h, o.ctypes.data)
+        return dict(nodes=int(o[0]), eval_rows=int(o[1]), eval_calls=int(o[2]), same_batch=int(o[3]),
+                    reservation=int(o[4]), node_count=int(o[5]), root_type=int(o[6]), root_visits=int(o[7]))
+
+    def root_q(self): return float(lib.ora_search_root_q(self.h))
+
+
+def hash_evaluator(planes):
+    planes = np.ascontiguousarray(planes, dtype=np.uint16).reshape(-1, 4736)
+    n = len(planes)
+    v = np.zeros(n, np.uint16); a = np.zeros((n, 4672), np.uint16); b = np.zeros((n, 4672), np.uint16)
+    w = np.zeros((n, 3), np.uint16); m = np.zeros(n, np.uint16)
+    lib.ora_hash_evaluator(planes.ctypes.data, n, v.ctypes.data, a.ctypes.data, b.ctypes.data, w.ctypes.data, m.ctypes.data)
+    return v, a, b, w, m

@@ -1,0 +1,75 @@
+"""GPU search parity: the wave-per-game MCGS (hm_sp_*) against the CPU oracle search
+(oracle/search.hpp, tie_mode=1 / exp_mode=1) under the shared deterministic hash evaluator:
+root edge lists (moves, visit counts, priors, Q), node counts and collision counters must be
+identical for every root."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _hash_eval_gpu(planes):
+    import torch
+    h = planes.cpu().numpy().view(np.uint16).reshape(-1, 4736)
+    v, a, b, w, m = O.hash_evaluator(h)
+    tc = lambda x: torch.from_numpy(x.view(np.float16)).cuda()
+    return tc(v), tc(a), tc(b), tc(w), tc(m)
+
+
+def test_rules_probe_matches_oracle(hm):
+    boards = np.concatenate([O.random_positions(21, 1500, 200), O.random_positions(22, 500, 40)])
+    out, keys = hm.rules_probe(hm.to_device(boards))
+    b = O.Board()
+    for i in range(len(boards)):
+        b.from_compact(boards[i:i + 1])
+        want = [b.is_checkmate(0, False), b.is_checkmate(0, True), b.is_checkmate(1, False), b.is_checkmate(1, True),
+                b.in_check(0), b.in_check(1)]
+        assert [bool(x) for x in out[i, :6]] == want, i
+        assert int(keys[i, 0]) == b.hash_key(False) and int(keys[i, 1]) == b.hash_key(True), i
+        assert int(keys[i, 2]) == int(O.lib.ora_rep_key(b.h, 0)) and int(keys[i, 3]) == int(O.lib.ora_rep_key(b.h, 1))
+
+
+def _roots(n, seed):
+    boards = O.random_positions(seed, n * 37, 90)[::37][:n].copy()
+    return boards
+
+
+@pytest.mark.parametrize("nodes,noise", [(400, False), (400, True), (100, False)])
+def test_search_matches_oracle(hm, nodes, noise):
+    G = 24
+    roots = _roots(G, 77 + nodes)
+    roots[0] = O.Board().compact(0, False)[0]
+    eng = hm.SearchEngine(G, 1700)
+    eng.set_games(roots)
+    seeds = (np.arange(G, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(12345)
+    alpha, eps = (0.3, 0.25) if noise else (0.0, 0.0)
+    eng.begin_search(nodes, seeds, alpha, eps)
+    eng.run(_hash_eval_gpu)
+    st = eng.root_stats()
+    exact = 0
+    for g in range(G):
+        b = O.Board()
+        b.from_compact(roots[g:g + 1])
+        s = O.Search(1, 1)
+        if noise:
+            s.set_noise(alpha, eps, int(seeds[g]))
+        ok = s.run(b, int(roots["team"][g]), bool(roots["time_adv"][g]), nodes)
+        info = st["info"][g]
+        if not ok:
+            assert info[0] == 4, (g, info)          # ST_NOACTION
+            continue
+        e = s.edges()
+        n = st["counts"][g]
+        oi = s.info()
+        assert info[8] == 0, ("overflow", g, info)
+        same = (n == len(e["visits"]) and np.array_equal(st["move_a"][g, :n], e["move_a"])
+                and np.array_equal(st["move_b"][g, :n], e["move_b"]) and np.array_equal(st["visits"][g, :n], e["visits"])
+                and np.array_equal(st["prior"][g, :n], e["prior"]) and np.array_equal(st["q"][g, :n], e["q"])
+                and info[1] == oi["nodes"] and info[2] == oi["eval_rows"] and info[5] == oi["node_count"])
+        assert same, (g, n, len(e["visits"]), info, oi, st["visits"][g, :n], e["visits"])
+        assert st["root_q"][g] == np.float32(s.root_q())
+        exact += 1
+    assert exact >= G - 4
+    eng.close()
