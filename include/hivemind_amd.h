@@ -212,6 +212,58 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
  * history-free boards (d_out: n*8 ints, d_keys: n*4 u64: hash_key(adv=0), hash_key(adv=1), repetition keys). */
 int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
 
+/* ================================================================== */
+/* self-play driver: run_selfplay (tools/selfplay.h:10-33,              */
+/* tools/selfplay.cc:558-748) for `concurrent_games` slots on one GPU.  */
+/* ================================================================== */
+typedef struct hm_selfplay hm_selfplay;
+
+typedef struct hm_selfplay_config {       /* SelfPlayConfig, tools/selfplay.h:10-31 */
+    uint64_t games, nodes, max_macro_plies, chunk_samples;
+    double   raw_policy_mean_macro_plies;
+    uint64_t raw_policy_max_macro_plies;
+    double   raw_policy_high_temperature_probability;
+    double   mcts_temperature, mcts_temperature_decay;
+    uint64_t mcts_temperature_plies;
+    float    resign_threshold;
+    uint64_t resign_consecutive_plies;
+    double   resign_disable_fraction;
+    double   node_random_factor;
+    float    dirichlet_alpha, dirichlet_epsilon;
+    uint64_t seed;                        /* 0 = wall clock, as the reference */
+    int      rank, world;                 /* games with index % world == rank are played here */
+    int      concurrent_games;            /* game slots searched in lockstep on this GPU */
+} hm_selfplay_config;
+void hm_selfplay_config_default(hm_selfplay_config* cfg);
+
+/* Evaluator seam (class Engine, nn/engine.h:43-81): device buffers owned by the caller.
+ * planes[k]: fp16 [concurrent_games*8, 74, 8, 8]; heads as in hm_sp_process. */
+typedef struct hm_eval_io {
+    void* planes[2];
+    void* value; void* pi_a; void* pi_b; void* wdl; void* moves_left;
+} hm_eval_io;
+/* Runs the network on the first `rows` rows of planes[which] and fills the head buffers
+ * (Engine::enqueueInferenceHalf + synchronizeInferenceHalf).  Return 0 on success. */
+typedef int (*hm_eval_fn)(void* user, int which, int rows);
+
+typedef struct hm_selfplay_result {
+    uint64_t games, samples, searched_positions, total_nodes, eval_rows, eval_batches, search_iterations, raw_plies;
+    uint64_t record_bytes;
+    uint64_t terminations[5];            /* macro-ply limit, checkmate, draw, resignation, no legal action */
+    double   seconds;
+} hm_selfplay_result;
+
+int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,
+                       hm_eval_fn fn, void* user, hm_selfplay** out);
+int hm_selfplay_run(hm_selfplay* sp, hm_selfplay_result* out);
+/* Serialized TrainingSample records of the finished games (HVM4 sample layout, selfplay.cc:126-142);
+ * returns the byte count; pointers stay valid until destroy. */
+uint64_t hm_selfplay_records(hm_selfplay* sp, const uint8_t** data, uint64_t* count);
+int hm_selfplay_destroy(hm_selfplay* sp);
+/* ChunkWriter::flush (selfplay.cc:105-151): header 'HVM4' u32 4, u16 74, u16 4672, u64 count + samples,
+ * published atomically via .tmp + rename. */
+int hm_hvm4_write_chunk(const char* path, const uint8_t* records, uint64_t nbytes, uint64_t count);
+
 #ifdef __cplusplus
 }
 #endif

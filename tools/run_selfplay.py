@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""hivemind selfplay --games G --nodes N (engine/src/main.cc:122-141) on this GPU."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hivemind_amd as hm
+from hivemind_amd import net as N
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--games", type=int, default=16)
+ap.add_argument("--nodes", type=int, default=100)
+ap.add_argument("--concurrent", type=int, default=16)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--model", default="small", choices=["small", "full"])
+ap.add_argument("--max-macro-plies", type=int, default=400)
+ap.add_argument("--out", default="gpurun_out/selfplay")
+ap.add_argument("--graph", action="store_true")
+a = ap.parse_args()
+hm.init(0)
+torch.manual_seed(0)
+model = N.rise_v3_small() if a.model == "small" else N.rise_v33()
+net = N.InferenceNet(model)
+if a.graph:
+    net.capture(a.concurrent * 8)
+cfg = hm.default_selfplay_config(games=a.games, nodes=a.nodes, seed=a.seed, concurrent_games=a.concurrent, max_macro_plies=a.max_macro_plies)
+sp = hm.SelfPlay(cfg, net)
+t = time.time()
+res = sp.run()
+dt = time.time() - t
+rec, cnt = sp.records()
+os.makedirs(a.out, exist_ok=True)
+path = os.path.join(a.out, f"chunk_{a.seed}_000000.hvm")
+hm.write_chunk(path, rec, cnt)
+samples = hm.read_hvm4(path)
+for s in samples:
+    for p in (s["policy_a"], s["policy_b"]):
+        assert abs(float(p["prob"].sum()) - 1.0) < 1e-4
+print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searched_positions, nodes=res.total_nodes,
+                      eval_rows=res.eval_rows, eval_batches=res.eval_batches, iters=res.search_iterations, raw=res.raw_plies,
+                      seconds=res.seconds, wall=dt, positions_per_s=res.samples / res.seconds, nodes_per_s=res.total_nodes / res.seconds,
+                      term=list(res.terminations), bytes=res.record_bytes, chunk_samples=len(samples))))
