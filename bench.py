@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — one JSON line per run (contract in the task statement).
 
-Workload (round 1): BASELINE.json configs[1] — batched plane-encode of 65 536 random Bughouse
-positions per GPU per step (fp16 planes, the dtype the reference feeds its net,
-searchthread.cc:413-418).  A "step" = one pass of the encoder over the batch, inputs resident
-in HBM.  N>1: every rank encodes its own batch (independent positions, no collective), weak
-scaling.  The CPU baseline leg times the oracle's encoder (kind "port": the reference's
-planes.cc needs CUDA headers this image lacks) on a bounded sample on rank 0 at N=1.
+Headline workload = BASELINE.json configs[2]: `selfplay --games 64 --nodes 400` with a random-init
+RISEv3-small on one MI355X (synthetic: no dataset, torch.manual_seed(0) weights).  A "step" is one
+complete self-play run of that configuration (fresh games, seed = base + step); `value` =
+HVM4 samples (searched root positions) written per second, whole job.  N>1: every rank plays its own
+64 games (games are the independent unit; the only exchange is the gather of finished records to
+rank 0, inside the timed region) -> weak scaling.
+
+`--workload planes` keeps the round-1 first bench (configs[1], batched plane-encode of 65 536
+positions); its numbers are also reported under "extra" of the default run, with joint perft.
 """
 import argparse
 import json
@@ -20,19 +23,92 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 N_POSITIONS = 65536
-BYTES_OUT = 4736 * 2          # fp16 planes written per position
-BYTES_IN = 208                # hm_board read per position
-HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def bench_planes(hm, dev, steps, warmup, rank):
+    boards = hm.random_positions(N_POSITIONS, seed=42 + rank)
+    out = torch.empty((N_POSITIONS, 74, 8, 8), dtype=torch.float16, device=dev)
+    for _ in range(warmup):
+        hm.board_to_planes(boards, "f16", out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        hm.board_to_planes(boards, "f16", out=out)
+        e.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    algo = N_POSITIONS * (4736 * 2 + 208)
+    return dict(positions_per_s=N_POSITIONS * steps / dt, kernel_ms=kern_ms, achieved_GBps=algo / (kern_ms * 1e-3) / 1e9,
+                hbm_frac=algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=algo), boards, out, dt
+
+
+def cpu_planes_baseline(boards, out, seconds=8.0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+    sample = 16384
+    hb = boards[:sample].cpu().numpy().view(O.BOARD_DTYPE).reshape(-1)
+    ob = np.zeros((sample, 4736), dtype=np.uint16)
+    reps, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < seconds:
+        O.lib.ora_time_planes(hb.ctypes.data, sample, 0, ob.ctypes.data, 8)
+        reps += 8
+    cdt = time.perf_counter() - t1
+    got = out[:sample].cpu().numpy().view(np.uint16).reshape(sample, -1)
+    assert np.array_equal(got, ob), "GPU planes differ from the oracle on the bench batch"
+    return dict(value=sample * reps / cdt, unit="positions/s", cores=1, kind="port",
+                sample=f"{sample} bench positions x {reps} passes, oracle planes_f16, 1 thread")
+
+
+def cpu_selfplay_baseline(model, nodes, seconds=20.0):
+    """Oracle single-thread reference-schedule search (oracle/search.hpp) with the same weights run by
+    torch on the host cores: searched positions per second on a bounded sample of start-of-game roots."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+    cpu_model = model.float().eval()
+
+    def ev(planes_u16):
+        x = torch.from_numpy(planes_u16.view(np.float16).astype(np.float32)).reshape(-1, 74, 8, 8)
+        with torch.no_grad():
+            v, a, b, w, m = cpu_model(x)
+        h = lambda t: t.to(torch.float16).contiguous().numpy().view(np.uint16)
+        return h(v.reshape(-1)), h(a), h(b), h(w), h(m.reshape(-1))
+    roots = O.random_positions(1234, 40 * 11, 40)[::11]
+    s = O.Search(1, 1)
+    s.set_evaluator(ev)
+    done, nodes_done, t0 = 0, 0, time.perf_counter()
+    for i in range(len(roots)):
+        b = O.Board()
+        b.from_compact(roots[i:i + 1])
+        if s.run(b, int(roots["team"][i]), bool(roots["time_adv"][i]), nodes):
+            done += 1
+            nodes_done += s.info()["nodes"]
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="positions/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{done} searches of {nodes} nodes from random-playout roots in {dt:.1f}s: oracle/search.hpp "
+                       f"(single search thread, B=8) + the same RISEv3-small weights on torch CPU fp32 "
+                       f"({torch.get_num_threads()} intra-op threads); {nodes_done / dt:.0f} nodes/s")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--perft-depth", type=int, default=4, help="extra: joint perft depth reported beside the metric (0 = skip)")
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="selfplay", choices=["selfplay", "planes"])
+    ap.add_argument("--games", type=int, default=64)
+    ap.add_argument("--nodes", type=int, default=400)
+    ap.add_argument("--model", default="small", choices=["small", "full"])
+    ap.add_argument("--perft-depth", type=int, default=5, help="extra: joint perft depth (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,86 +122,117 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import hivemind_amd as hm
+    from hivemind_amd import net as N
     hm.init(local)
     dev = torch.device("cuda", local)
-
-    boards = hm.random_positions(N_POSITIONS, seed=42 + rank)
-    out = torch.empty((N_POSITIONS, 74, 8, 8), dtype=torch.float16, device=dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        hm.board_to_planes(boards, "f16", out=out)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        hm.board_to_planes(boards, "f16", out=out)
-        e.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
-    value = world * N_POSITIONS * args.steps / dt
-    algo_bytes = N_POSITIONS * (BYTES_OUT + BYTES_IN)
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
-    extra = {}
-    if args.perft_depth > 0:
-        # second metric of BASELINE.json: joint perft nodes/s; ply-2 frontier striped over ranks
-        nodes, secs = hm.perft(args.perft_depth, shard=rank, nshards=world)
-        tot = torch.tensor([float(nodes), secs], dtype=torch.float64, device=dev)
-        if dist is not None:
-            n_all = tot[0:1].clone(); s_all = tot[1:2].clone()
-            dist.all_reduce(n_all, op=dist.ReduceOp.SUM)
-            dist.all_reduce(s_all, op=dist.ReduceOp.MAX)
-            nodes, secs = int(n_all.item()), float(s_all.item())
-        extra["perft"] = {"depth": args.perft_depth, "nodes": int(nodes), "seconds": secs,
-                          "nodes_per_s": nodes / secs if secs > 0 else None}
+    extra, cpu, line = {}, None, None
+    if args.workload == "planes":
+        steps, warmup = max(args.steps, 50), max(args.warmup, 5)
+        barrier()
+        pl, boards, out, dt = bench_planes(hm, dev, steps, warmup, rank)
+        dt = max_over_ranks(dt)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_planes_baseline(boards, out)
+        line = dict(metric="plane-encode positions/sec (BASELINE configs[1])", value=world * N_POSITIONS * steps / dt, unit="positions/s",
+                    steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3, dtype="u64",
+                    config={"workload": "batched plane-encode of 65536 random-playout Bughouse positions per GPU, fp16 out"},
+                    roofline={"bound": "hbm", "achieved": pl["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pl["hbm_frac"],
+                              "traffic": None, "kernel": "encode_planes_kernel<f16>", "kernel_ms": pl["kernel_ms"],
+                              "algorithmic_bytes_per_launch": pl["algorithmic_bytes_per_launch"]})
+    else:
+        torch.manual_seed(0)
+        model = N.rise_v3_small() if args.model == "small" else N.rise_v33()
+        flops = N.flops_per_position(model)
+        net = N.InferenceNet(model, device=dev).capture(args.games * 8)
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_py as O                     # checker / baseline leg only
-        sample = 16384
-        hb = boards[:sample].cpu().numpy().view(O.BOARD_DTYPE).reshape(-1)
-        ob = np.zeros((sample, 4736), dtype=np.uint16)
-        reps = 0
-        t1 = time.perf_counter()
-        while time.perf_counter() - t1 < 10.0:
-            O.lib.ora_time_planes(hb.ctypes.data, sample, 0, ob.ctypes.data, 8)
-            reps += 8
-        cdt = time.perf_counter() - t1
-        got = out[:sample].cpu().numpy().view(np.uint16).reshape(sample, -1)
-        assert np.array_equal(got, ob), "GPU planes differ from the oracle on the bench batch"
-        cpu = {"value": sample * reps / cdt, "unit": "positions/s", "cores": 1, "kind": "port",
-               "sample": f"{sample} of the {N_POSITIONS} bench positions x {reps} passes, oracle planes_f16, 1 thread"}
+        def one_run(seed):
+            cfg = hm.default_selfplay_config(games=args.games * world, nodes=args.nodes, seed=seed, concurrent_games=args.games,
+                                             rank=rank, world=world)
+            sp = hm.SelfPlay(cfg, net, device=dev)
+            res = sp.run()
+            rec, cnt = sp.records()
+            rec, cnt = hm.gather_records(rec, cnt, dist)          # the only cross-GPU exchange
+            sp.close()
+            return res, rec, cnt
+        for w in range(args.warmup):
+            one_run(1000 + w)
+        tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            res, rec, cnt = one_run(1 + k)
+            tot["samples"] += res.samples; tot["nodes"] += res.total_nodes; tot["eval_rows"] += res.eval_rows
+            tot["iters"] += res.search_iterations; tot["collect_ms"] += res.collect_ms; tot["eval_ms"] += res.eval_ms
+            tot["process_ms"] += res.process_ms; tot["nv"] += res.nodes_visited; tot["es"] += res.edges_scanned
+            tot["games"] += res.games; tot["bytes"] += rec.size
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        samples = sum_over_ranks(tot["samples"])
+        nodes = sum_over_ranks(tot["nodes"])
+        it = max(tot["iters"], 1)
+        legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
+                "k_process (expand+backup)": tot["process_ms"] / it}
+        dominant = max(legs, key=legs.get)
+        if dominant.startswith("RISEv3"):
+            rows = args.games * 8
+            ach = rows * flops / (legs[dominant] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                    "traffic": None, "kernel": dominant, "kernel_ms": legs[dominant],
+                    "algorithmic_flops_per_launch": rows * flops}
+        else:
+            # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node
+            by = (tot["nv"] * (64 + 104) + tot["es"] * 40) / it
+            ach = by / (legs[dominant] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": dominant, "kernel_ms": legs[dominant], "algorithmic_bytes_per_launch": by,
+                    "note": "latency-bound pointer chase: one wavefront per game; see DESIGN.md"}
+        extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
+                             "lockstep_iterations": tot["iters"], "leg_ms_per_iteration": legs,
+                             "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_selfplay_baseline(model, args.nodes)
+        line = dict(metric="self-play positions/sec @ nodes=400", value=samples / dt, unit="positions/s", steps=args.steps,
+                    warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, dtype="fp16 net / u64 board / f32 tree",
+                    config={"workload": f"selfplay --games {args.games} --nodes {args.nodes} per GPU, random-init RISEv3-{args.model} "
+                                        f"(torch.manual_seed(0)), B=8 single-thread reference schedule per game",
+                            "games_per_gpu": args.games, "nodes": args.nodes, "sharding": f"games x{world}, record gather only"},
+                    roofline=roof)
+        if not args.no_extra and world == 1:
+            pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
+            extra["plane_encode_64k"] = pl
+            if rank == 0 and not args.no_cpu_baseline:
+                extra["plane_encode_64k"]["cpu_baseline"] = cpu_planes_baseline(boards, out, 5.0)
+        if not args.no_extra and args.perft_depth > 0:
+            n, secs = hm.perft(args.perft_depth, shard=rank, nshards=world)
+            n, secs = int(sum_over_ranks(n)), max_over_ranks(secs)
+            extra["perft"] = {"depth": args.perft_depth, "nodes": n, "seconds": secs, "nodes_per_s": n / secs if secs > 0 else None}
 
     if rank == 0:
-        line = {
-            "metric": "plane-encode positions/sec (BASELINE configs[1]; self-play positions/sec pending the GPU search)",
-            "value": value, "unit": "positions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "batched plane-encode of 65536 random-playout Bughouse positions per GPU, fp16 out",
-                       "positions_per_gpu": N_POSITIONS, "sharding": f"positions x{world}, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "encode_planes_kernel<f16>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes},
-            "cpu_baseline": cpu,
-            "extra": extra,
-        }
-        print(json.dumps(line), flush=True)
+        line.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                     "cpu_baseline": cpu, "extra": extra})
+        order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline", "extra"]
+        print(json.dumps({k: line[k] for k in order}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -66,12 +66,14 @@ __device__ inline u64 board_hash_key(const P& A, const P& B, const Hist& hA, con
     combined ^= rc + 0x9e3779b97f4a7c15ULL + (combined << 6) + (combined >> 2);
     return adv ? (combined ^ timeAdvKey) : combined;
 }
-// occurrences of the current (last) key in the whole history, current included (board.h:326-332)
+// occurrences of the current (last) key in the whole history, current included (board.h:326-332).
+// Wave-cooperative: call with all 64 lanes active and identical arguments; lanes stride the keys.
 __device__ inline int repetition_count(const Hist& h) {
     if (h.len <= 0) return 0;
     const u64 cur = h.keys[h.len - 1];
     int c = 0;
-    for (int i = 0; i < h.len; ++i) c += h.keys[i] == cur;
+    for (int i = threadIdx.x & 63; i < h.len; i += 64) c += h.keys[i] == cur;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     return c;
 }
 __device__ inline bool is_draw_on_board(const P& p, const Hist& h, int ply) {   // board.h:423-453
@@ -79,9 +81,9 @@ __device__ inline bool is_draw_on_board(const P& p, const Hist& h, int ply) {   
     const int threshold = ply > 0 ? 1 : 2;
     const u64 cur = h.keys[h.len - 1];
     int c = 0;
-    for (int i = 0; i + 1 < h.len; ++i)
-        if (h.keys[i] == cur && ++c >= threshold) return true;
-    return false;
+    for (int i = threadIdx.x & 63; i + 1 < h.len; i += 64) c += h.keys[i] == cur;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    return c >= threshold;
 }
 
 __device__ __forceinline__ u64 checkers_of(const AttackTab& t, const P& p) {
@@ -237,7 +239,9 @@ __device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, con
             bool d = nb[active].rule50 >= 100;
             if (!d) {   // threshold 1 (ply > 0): any earlier occurrence
                 const Hist h0 = hist_of(j, active);
-                for (int i = 0; i < h0.len; ++i) if (h0.keys[i] == k) { d = true; break; }
+                bool f = false;
+                for (int i = threadIdx.x & 63; i < h0.len; i += 64) f |= h0.keys[i] == k;
+                d = __ballot(f) != 0ULL;
             }
             drawAfter = d || is_draw_on_board(nb[waiting], hist_of(j, waiting), searchPly + 1);
         } else {

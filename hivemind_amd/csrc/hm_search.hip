@@ -106,7 +106,7 @@ struct Game {
     float alpha, eps;
     u64 noiseSeed, rootHash;
     int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
-    int nA_noise, nB_noise;
+    int nodesVisited, edgesScanned;     // traversal traffic counters (roofline accounting)
 };
 
 struct Params {          // device-visible configuration + pool geometry
@@ -174,6 +174,13 @@ __device__ __forceinline__ float h2f(uint16_t h) {
 }
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_int(v) & 0x7f800000) != 0x7f800000; }
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ULL; }
+__device__ __forceinline__ bool wave_all(bool p) { return __ballot(!p) == 0ULL; }
+__device__ __forceinline__ int wave_sum_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 struct G {               // per-wave view of one game's pools
     Game* g;
@@ -265,8 +272,8 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCand
         if (a >= h.nA || b >= h.nB) continue;
         u32* vis = reinterpret_cast<u32*>(s.arena + h.visited);
         bool seen = false;
-        for (u32 i = 0; i < h.visSize; ++i) seen |= vis[i] == key;
-        if (seen) continue;
+        for (u32 i = threadIdx.x & 63; i < h.visSize; i += 64) seen |= vis[i] == key;   // lane-parallel membership test
+        if (wave_any(seen)) continue;
         if (h.visSize >= h.visCap) { gen_grow(s, h.visited, h.visCap, h.visSize, 4); vis = reinterpret_cast<u32*>(s.arena + h.visited); }
         if (h.visSize >= h.visCap) return;
         vis[h.visSize++] = key;
@@ -322,16 +329,23 @@ __device__ inline Edge* edge_append(G& s, Node& n) {
     return edges_of(s, n) + n.expanded;
 }
 
-// node.h:151-175
+// node.h:151-175 — edges scanned lane-parallel (one edge per lane), wave-reduced
 __device__ inline bool should_expand_new_child(G& s, const Node& n) {
+    const int lane = threadIdx.x & 63;
     const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
     const Edge* e = edges_of(s, n);
-    bool allLose = n.expanded > 0;
-    bool anyUnvisited = false;
-    for (int i = 0; i < n.expanded; ++i) {
-        allLose &= s.nodes[e[i].child].type == T_WIN;
-        anyUnvisited |= (e[i].visits + e[i].vloss) == 0;
+    bool allLose = true, anyUnvisited = false;
+    for (int base = 0; base < n.expanded; base += 64) {
+        const int i = base + lane;
+        if (i < n.expanded) {
+            const int child = e[i].child;
+            const int ev = e[i].visits + e[i].vloss;
+            allLose &= s.nodes[child].type == T_WIN;
+            anyUnvisited |= ev == 0;
+        }
     }
+    allLose = n.expanded > 0 && wave_all(allLose);
+    anyUnvisited = wave_any(anyUnvisited);
     if (hasNext && allLose) return true;
     if (anyUnvisited) return false;
     int v = n.visits + n.vvsum;
@@ -424,10 +438,25 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
     const float explorationBase = c * sqrtVisits;
     float visitedPolicySum = 0.0f;
     bool hasNonLosing = false;
-    // sequential (index-order) float sum: the reference adds childPriors in a plain loop
-    for (int i = 0; i < limit; ++i) {
-        if (s.prm->enableDynamicFpu && visits > 0 && e[i].visits + e[i].vloss > 0) visitedPolicySum += e[i].prior;
-        hasNonLosing |= s.nodes[e[i].child].type != T_WIN;
+    // edges are loaded lane-parallel; the prior sum is then accumulated in index order (the
+    // reference adds childPriors in a plain loop) from registers via shuffles
+    for (int base = 0; base < limit; base += 64) {
+        const int i = base + lane;
+        float pr = 0.0f;
+        bool counted = false, nonLosing = false;
+        if (i < limit) {
+            const Edge ed = e[i];
+            pr = ed.prior;
+            counted = s.prm->enableDynamicFpu && visits > 0 && (ed.visits + ed.vloss > 0);
+            nonLosing = s.nodes[ed.child].type != T_WIN;
+        }
+        hasNonLosing |= wave_any(nonLosing);
+        const u64 cmask = __ballot(counted);
+        const int cnt = limit - base < 64 ? limit - base : 64;
+        for (int k = 0; k < cnt; ++k) {
+            const float pk = __shfl(pr, k);
+            if ((cmask >> k) & 1) visitedPolicySum += pk;
+        }
     }
     hasNonLosing &= n.type == T_UNSOLVED;
     const float parentQ = visits > 0 ? (n.valueSum / (float)visits) : 0.0f;
@@ -538,6 +567,7 @@ __device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajE
     p.len = 1;
     while (true) {
         Node n = s.nodes[cur];
+        s.g->nodesVisited++; s.g->edgesScanned += n.expanded;
         if (n.type != T_UNSOLVED) break;
         if (!(n.flags & F_EXPANDED)) {
             if (!reserved) {
@@ -954,13 +984,14 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
                 // hm_board image in LDS for the plane writer
                 wave_fence();
                 hm_board* hb = reinterpret_cast<hm_board*>(L.board);
+                const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
                 if (lane == 0) {
                     hb->pos[0] = ctx.pos[0]; hb->pos[1] = ctx.pos[1];
                     // last move per board: deepest path move on that board, else the game's last move
                     u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
                     for (int i = 1; i < p.len; ++i) { if (L.traj[i].moveA) lm[0] = L.traj[i].moveA; if (L.traj[i].moveB) lm[1] = L.traj[i].moveB; }
                     hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
-                    for (int b = 0; b < 2; ++b) { int rc = repetition_count(hist_of(p.jb, b)); hb->rep_count[b] = (uint8_t)(rc > 3 ? 3 : rc); }
+                    hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
                     hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
                 }
                 wave_fence();
@@ -1058,6 +1089,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     gm.nodeCount = 0; gm.arenaTop = 1; gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
     gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
     gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
+    gm.nodesVisited = gm.edgesScanned = 0;
     gm.targetNodes = targetNodes[g]; gm.noiseSeed = noiseSeeds ? noiseSeeds[g] : 0; gm.alpha = alpha; gm.eps = eps;
     gm.root = -1;
     Path p;
@@ -1074,54 +1106,92 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     if (is_checkmate(rt, p.jb.bd, team ^ 1, !adv, scratch) || mateUs || jb_is_draw(p.jb, 0)) { gm.status = ST_NOACTION; return; }
     const int cA = aOn ? count_legal(rt.att, p.jb.bd[0]) : 0, cB = bOn ? count_legal(rt.att, p.jb.bd[1]) : 0;
     if (cA + cB == 0 && !canWait) { gm.status = ST_NOACTION; return; }
-    // ---- find_immediate_root_mate (agent.cc:136-238)
+    // ---- find_immediate_root_mate (agent.cc:136-238).  The reference walks the candidates
+    // sequentially; here every candidate is pre-filtered lane-parallel with a necessary condition
+    // for Board::is_checkmate (some on-turn board of the victim has no legal move), and only the
+    // survivors are verified, in the reference's order, with the full rule.
     {
         u32* la = L.lists[6];
         u32* lb = L.lists[7];
-        int nA = aOn ? gen_legal(rt.att, p.jb.bd[0], la) : 0;
-        int nB = bOn ? gen_legal(rt.att, p.jb.bd[1], lb) : 0;
+        u32* flA = L.lists[2];
+        u32* flB = L.lists[3];
+        u32* ord = L.lists[4];           // low 16: A order, high 16: B order (stable_partition by gives_check)
+        u32* hits = L.lists[5];
+        int nA = 0, nB = 0;
+        if (lane == 0 && aOn) nA = gen_legal(rt.att, p.jb.bd[0], la);
+        if (lane == 1 && bOn) nB = gen_legal(rt.att, p.jb.bd[1], lb);
+        nA = __shfl(nA, 0); nB = __shfl(nB, 1);
+        __builtin_amdgcn_wave_barrier();
         const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;
-        // stable_partition: checking moves first (order within each class kept)
-        for (int b = 0; b < 2; ++b) {
-            u32* l = b == 0 ? la : lb;
-            const int n = b == 0 ? nA : nB;
-            u32* tmp = L.lists[5];
+        for (int i = lane; i < nA; i += 64) flA[i] = (gives_check(rt, p.jb.bd[0], la[i]) ? 1u : 0u) | (is_capture(p.jb.bd[0], la[i]) ? 2u : 0u);
+        for (int i = lane; i < nB; i += 64) flB[i] = (gives_check(rt, p.jb.bd[1], lb[i]) ? 1u : 0u) | (is_capture(p.jb.bd[1], lb[i]) ? 2u : 0u);
+        __builtin_amdgcn_wave_barrier();
+        {
             int k = 0;
-            for (int i = 0; i < n; ++i) if (gives_check(rt, p.jb.bd[b], l[i])) tmp[k++] = l[i];
-            for (int i = 0; i < n; ++i) if (!gives_check(rt, p.jb.bd[b], l[i])) tmp[k++] = l[i];
-            for (int i = 0; i < n; ++i) l[i] = tmp[i];
+            for (int i = 0; i < nA; ++i) if (flA[i] & 1) ord[k++] = (u32)i;
+            for (int i = 0; i < nA; ++i) if (!(flA[i] & 1)) ord[k++] = (u32)i;
+            for (int i = nA; i < HM_MAX_MOVES; ++i) if (i < nB) ord[i] = 0;
+            k = 0;
+            for (int i = 0; i < nB; ++i) if (flB[i] & 1) { ord[k] = (ord[k] & 0xffffu) | ((u32)i << 16); k++; }
+            for (int i = 0; i < nB; ++i) if (!(flB[i] & 1)) { ord[k] = (ord[k] & 0xffffu) | ((u32)i << 16); k++; }
         }
+        __builtin_amdgcn_wave_barrier();
+        const int victim = team ^ 1;
+        auto no_move_board = [&](const P* nb) {   // necessary condition for is_checkmate(victim, .)
+            const bool vA = (int)nb[0].stm == victim, vB = (int)nb[1].stm == (victim ^ 1);
+            return (vA && count_legal(rt.att, nb[0]) == 0) || (vB && count_legal(rt.att, nb[1]) == 0);
+        };
+        u32* hitCount = reinterpret_cast<u32*>(&L.unavail[0]);
         bool found = false;
         u32 fa = 0, fb = 0;
-        for (int b = 0; b < 2 && !found; ++b) {
-            const bool on = b == 0 ? aOn : bOn, otherOn = b == 0 ? bOn : aOn;
+        // phases 1/2: a move on one board, pass on the other; phase 3: a move on both boards
+        for (int phase = 0; phase < 3 && !found; ++phase) {
+            const bool on = phase == 0 ? aOn : phase == 1 ? bOn : (aOn && bOn);
             if (!on) continue;
-            const u32* l = b == 0 ? la : lb;
-            const int n = b == 0 ? nA : nB;
-            for (int i = 0; i < n && !found; ++i) {
-                const u32 m = l[i];
-                if (!aChk && !bChk && !gives_check(rt, p.jb.bd[b], m)) continue;
-                const bool cap = is_capture(p.jb.bd[b], m);
-                if (!otherOn || is_single_pass_legal(adv, aOn, bOn, cap)) {
-                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
-                    const int h = do_move(rt.att, rt.zob, nb[b], m);
-                    if (h) add_to_hand(rt.zob, nb[1 - b], h);
-                    if (is_checkmate(rt, nb, team ^ 1, !adv, scratch)) { found = true; if (b == 0) fa = m; else fb = m; }
+            const int total = phase == 0 ? nA : phase == 1 ? nB : nA * nB;
+            if (lane == 0) *hitCount = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < total; t += 64) {
+                u32 mA = 0, mB = 0;
+                bool consider;
+                if (phase == 0) {
+                    const int i = (int)(ord[t] & 0xffffu);
+                    mA = la[i];
+                    consider = (aChk || bChk || (flA[i] & 1)) && (!bOn || is_single_pass_legal(adv, aOn, bOn, (flA[i] & 2) != 0));
+                } else if (phase == 1) {
+                    const int i = (int)(ord[t] >> 16);
+                    mB = lb[i];
+                    consider = (aChk || bChk || (flB[i] & 1)) && (!aOn || is_single_pass_legal(adv, aOn, bOn, (flB[i] & 2) != 0));
+                } else {
+                    const int i = (int)(ord[t / nB] & 0xffffu), j = (int)(ord[t % nB] >> 16);
+                    mA = la[i]; mB = lb[j];
+                    consider = aChk || bChk || (flA[i] & 1) || (flB[j] & 1);
                 }
+                if (!consider) continue;
+                P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
+                if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; }
             }
-        }
-        if (!found && aOn && bOn) {
-            for (int i = 0; i < nA && !found; ++i) {
-                const u32 mA = la[i];
-                const bool chkA = gives_check(rt, p.jb.bd[0], mA);
-                for (int j = 0; j < nB && !found; ++j) {
-                    const u32 mB = lb[j];
-                    if (!aChk && !bChk && !chkA && !gives_check(rt, p.jb.bd[1], mB)) continue;
-                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
-                    make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
-                    if (is_checkmate(rt, nb, team ^ 1, !adv, scratch)) { found = true; fa = mA; fb = mB; }
-                }
+            __builtin_amdgcn_wave_barrier();
+            int nh = (int)*hitCount;
+            if (nh > HM_MAX_MOVES) nh = HM_MAX_MOVES;
+            // verify survivors in candidate order
+            u32 last = 0;
+            bool first = true;
+            for (int r = 0; r < nh && !found; ++r) {
+                u32 best = 0xffffffffu;
+                for (int q = 0; q < nh; ++q) { const u32 v = hits[q]; if ((first || v > last) && v < best) best = v; }
+                if (best == 0xffffffffu) break;
+                last = best; first = false;
+                u32 mA = 0, mB = 0;
+                if (phase == 0) mA = la[ord[best] & 0xffffu];
+                else if (phase == 1) mB = lb[ord[best] >> 16];
+                else { mA = la[ord[best / nB] & 0xffffu]; mB = lb[ord[best % nB] >> 16]; }
+                P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
+                if (is_checkmate(rt, nb, victim, !adv, scratch)) { found = true; fa = mA; fb = mB; }
             }
+            __builtin_amdgcn_wave_barrier();
         }
         if (found) {   // agent.cc:458-499: trivial proven tree
             const int root = node_alloc(s, team, 0);
@@ -1173,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         int* inf = o.info + (size_t)g * 12;
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
-        inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = (int)gm.arenaTop; inf[11] = gm.ttCount;
+        inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;
     }
 }
 
@@ -1235,11 +1305,12 @@ __global__ __launch_bounds__(64) void k_game_state(Pools pl, Params prm, hm_boar
     path_reset(s, p);
     const bool mate = is_checkmate(s_rt, p.jb.bd, s.g->team, s.g->adv != 0, scratch);
     const bool draw = jb_is_draw(p.jb, 0);
+    const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
     if (lane == 0) {
         hm_board hb;
         hb.pos[0] = s.g->pos[0]; hb.pos[1] = s.g->pos[1];
         hb.last_move[0] = s.g->lastMove[0]; hb.last_move[1] = s.g->lastMove[1];
-        for (int b = 0; b < 2; ++b) { int rc = repetition_count(hist_of(p.jb, b)); hb.rep_count[b] = (uint8_t)(rc > 3 ? 3 : rc); }
+        hb.rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb.rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
         hb.team = (uint8_t)s.g->team; hb.time_adv = (uint8_t)s.g->adv; hb.reserved = 0;
         out[g] = hb;
         flags[g] = (mate ? 1 : 0) | (draw ? 2 : 0);
@@ -1607,6 +1678,12 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+// number of games still searching after the last hm_sp_process (synchronises the null stream)
+int hm_sp_active(hm_sp* sp, int* active) {
+    if (!sp || !active) return hm_fail(HM_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpy(active, sp->d_active, sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
     if (!sp || !move_a || !move_b) return hm_fail(HM_ERR_INVALID, "null argument");

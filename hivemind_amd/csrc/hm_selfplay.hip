@@ -31,6 +31,7 @@
 #include "../../include/hivemind_amd.h"
 
 int hm_fail(int code, const std::string& msg);
+extern "C" int hm_sp_active(hm_sp* sp, int* active);
 
 namespace {
 
@@ -109,6 +110,7 @@ struct hm_selfplay {
     hm_board* d_boards = nullptr;
     uint8_t* d_u8 = nullptr;
     std::vector<uint64_t> termCounts = std::vector<uint64_t>(5, 0);
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static bool start_game(hm_selfplay* s, Slot& sl, hm_board& out) {
@@ -164,10 +166,20 @@ static void finish_game(hm_selfplay* s, Slot& sl) {   // selfplay.cc:726-734
 
 static int run_search_lockstep(hm_selfplay* s) {
     int which = 0, active = 1, iters = 0;
+    if (!s->ev[0]) for (auto& e : s->ev) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
     while (active > 0) {
+        (void)hipEventRecord(s->ev[0], nullptr);
         if (int rc = hm_sp_collect(s->sp, s->io.planes[which], s->io.planes[1 - which], nullptr)) return rc;
+        (void)hipEventRecord(s->ev[1], nullptr);
         if (int rc = s->fn(s->user, which, s->G * 8)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
-        if (int rc = hm_sp_process(s->sp, s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, &active, nullptr)) return rc;
+        (void)hipEventRecord(s->ev[2], nullptr);
+        if (int rc = hm_sp_process(s->sp, s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr, nullptr)) return rc;
+        (void)hipEventRecord(s->ev[3], nullptr);
+        if (int rc = hm_sp_active(s->sp, &active)) return rc;     // syncs the stream
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) s->res.collect_ms += ms;
+        if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) s->res.eval_ms += ms;
+        if (hipEventElapsedTime(&ms, s->ev[2], s->ev[3]) == hipSuccess) s->res.process_ms += ms;
         which = 1 - which;
         s->res.eval_batches += 1;
         if (++iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
@@ -364,6 +376,8 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
             if (info[(size_t)g * 12 + 8]) return hm_fail(HM_ERR_OVERFLOW, "search pool overflow in game slot " + std::to_string(g) + " (flags " + std::to_string(info[(size_t)g * 12 + 8]) + ")");
             s->res.searched_positions += 1;
             s->res.eval_rows += (uint64_t)info[(size_t)g * 12 + 2];
+            s->res.nodes_visited += (uint64_t)info[(size_t)g * 12 + 10];
+            s->res.edges_scanned += (uint64_t)info[(size_t)g * 12 + 11];
             const int n = counts[g];
             if (n == 0) { sl.winner = sl.team == HM_WHITE ? 1 : 0; sl.termination = 4; finish_game(s, sl); continue; }
             const hm_move* ea = mA.data() + (size_t)g * E;

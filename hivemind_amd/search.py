@@ -35,6 +35,7 @@ _SIGS = {
     "hm_sp_collect": (_i, [_vp, _vp, _vp, _vp]),
     "hm_sp_process": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp]),
     "hm_sp_max_edges": (_i, [_vp]),
+    "hm_sp_active": (_i, [_vp, C.POINTER(_i)]),
     "hm_sp_root_stats": (_i, [_vp] + [_vp] * 8 + [_i]),
     "hm_sp_apply": (_i, [_vp, _vp, _vp, _vp]),
     "hm_sp_game_state": (_i, [_vp, _vp, _vp, _vp]),

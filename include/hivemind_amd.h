@@ -190,10 +190,12 @@ int hm_sp_collect(hm_sp* sp, void* d_planes_cur, void* d_planes_next, void* stre
 /* active_games (host, optional): number of games still searching after this step (forces a sync). */
 int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl,
                   const void* d_moves_left, int* active_games, void* stream);
+/* Games still searching after the last hm_sp_process (synchronises). */
+int hm_sp_active(hm_sp* sp, int* active);
 /* Agent::root_edge_stats / root_q (agent.cc:1004-1024) for all games -> host arrays
  * [n_games][max_edges]; info[g][12] = status, nodes, eval rows, same-batch collisions,
  * reservation collisions, node count, root type, root visits, overflow flags, max depth,
- * arena words, TT entries. */
+ * tree nodes visited and edges scanned during selection (traffic accounting). */
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
                      float* root_q, int* info, int max_edges);
@@ -251,6 +253,9 @@ typedef struct hm_selfplay_result {
     uint64_t record_bytes;
     uint64_t terminations[5];            /* macro-ply limit, checkmate, draw, resignation, no legal action */
     double   seconds;
+    /* device time of the three legs of a lockstep iteration, HIP events on the launch stream */
+    double   collect_ms, eval_ms, process_ms;
+    uint64_t nodes_visited, edges_scanned;   /* tree nodes / edges read by selection (roofline accounting) */
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,
