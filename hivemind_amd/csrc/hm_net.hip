@@ -1,0 +1,376 @@
+// hm_net.hip — RISEv3 forward as ONE gfx950 kernel launch (the evaluator's hot op).
+//
+// Replaces the TensorRT FP16 plan of nn/engine.cc:290-401,577-650 for the network of
+// src/architectures/rise_mobile_v3.py:105-230 (deployed form: BatchNorm folded, ECA reduced to its
+// centre tap).  Design for MI355X, small-batch regime of the search (a few hundred rows):
+//   * one workgroup (4 waves) owns one position for the whole network: its 8x8xC activation tile
+//     lives in LDS from the stem to the heads, so the only HBM traffic is the 9.5 KB of input
+//     planes, the 18.7 KB of policy logits and the (L2-resident) weights;
+//   * every convolution is an MFMA GEMM with M = the 64 squares: 1x1 convs directly, 3x3 convs as an
+//     implicit im2col over the LDS tile (a zero row stands in for off-board taps); weights are
+//     pre-packed on the host in v_mfma_f32_32x32x16_f16 fragment order, so a wave fetches a B (or
+//     transposed A) fragment with one coalesced 1 KiB load and never stages weights through LDS;
+//   * the mobile block is fused end to end: 1x1 expand (+bias, ReLU) -> LDS [ch][sq] -> depthwise
+//     kxk on the VALU (+bias, ReLU) -> LDS [sq][ch] -> 1x1 project accumulated in registers across
+//     64-channel chunks -> + bias + (ECA-gated) residual -> back into the LDS tile.
+// Launch overhead and the ~100 small kernels of the library path disappear; the kernel is bound by
+// MFMA issue + LDS fragment reads (M = 64 rows per workgroup), not by HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/hivemind_amd.h"
+
+int hm_fail(int code, const std::string& msg);
+
+namespace hmn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16;
+
+constexpr int MAXB = 16;
+struct BlockDesc {
+    int cop, k, eca, pad;
+    unsigned w1, dw, w2, ecaw;     // fp16 buffer offsets (in halfs)
+    unsigned b1, b2, b3, ecab;     // fp32 buffer offsets (in floats)
+};
+struct NetDesc {
+    int C, nblocks, cv, cin_pad;   // trunk channels, #blocks, value-head channels, padded input channels (80)
+    unsigned stem_w, ps_w, pp_w, v_w, vl_w;    // fp16 offsets
+    unsigned stem_b, ps_b, v_b, vl_b;          // fp32 offsets
+    BlockDesc blk[MAXB];
+};
+
+__device__ __forceinline__ floatx16 mfma(half8 a, half8 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx16 zero16() {
+    floatx16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+// packed fragment (kstep, tile) of a [K][N] matrix: lane l holds W[kstep*16 + 8*(l>>5) + j][tile*32 + (l&31)]
+__device__ __forceinline__ half8 wfrag(const h16* w, int ntiles, int kstep, int tile, int lane) {
+    return reinterpret_cast<const half8*>(w)[(size_t)(kstep * ntiles + tile) * 64 + lane];
+}
+// D element (reg) of a 32x32 tile: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+__device__ __forceinline__ int drow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// GEMM with M = 64 squares (2 row tiles) and N = ncol output channels, A from an LDS activation tile.
+//   conv3 = false: A[sq][k] = act[sq][k]                      (K = kdim)
+//   conv3 = true : A[sq][tap*cin + ci] = act[sq + shift(tap)][ci] or 0   (3x3, zero padding; K = 9*cin)
+// Wave w computes row tile (w & 1) and column tiles (w >> 1) + 2*i.  acc must hold ncol/64 tiles.
+template <int MAXT>
+__device__ __forceinline__ void gemm_rows(floatx16 (&acc)[MAXT], const h16* act, int lda, int zeroRow, bool conv3, int cin,
+                                          int ksteps, const h16* w, int ncol, int wave, int lane) {
+    const int ntiles = ncol >> 5;
+    const int rt = wave & 1;
+    const int sq = rt * 32 + (lane & 31);
+    const int f = sq & 7, r = sq >> 3;
+    const int kh = 8 * (lane >> 5);
+    const int nt = ntiles >> 1;                       // tiles per wave
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int k0 = ks * 16 + kh;
+        int row = sq, col = k0;
+        if (conv3) {
+            const int tap = k0 / cin;
+            col = k0 - tap * cin;
+            const int dr = tap / 3 - 1, df = tap % 3 - 1;
+            const int rr = r + dr, ff = f + df;
+            row = (rr >= 0 && rr < 8 && ff >= 0 && ff < 8) ? rr * 8 + ff : zeroRow;
+        }
+        const half8 a = *reinterpret_cast<const half8*>(act + (size_t)row * lda + col);
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            if (i < nt) {
+                const int tile = (wave >> 1) + 2 * i;
+                acc[i] = mfma(a, wfrag(w, ntiles, ks, tile, lane), acc[i]);
+            }
+        }
+    }
+}
+
+// Transposed GEMM: D[ch][sq] = sum_k W[k][ch] * act[sq][k]; 64 (or 32) output channels x 64 squares,
+// one 32x32 tile per wave (ch tile = wave >> 1, sq tile = wave & 1).  `wtile0` = first channel tile.
+__device__ __forceinline__ floatx16 gemm_cols(const h16* act, int lda, int zeroRow, bool conv3, int cin, int ksteps,
+                                              const h16* w, int ntilesTotal, int wtile, int wave, int lane) {
+    floatx16 acc = zero16();
+    const int sq = (wave & 1) * 32 + (lane & 31);
+    const int f = sq & 7, r = sq >> 3;
+    const int kh = 8 * (lane >> 5);
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int k0 = ks * 16 + kh;
+        int row = sq, col = k0;
+        if (conv3) {
+            const int tap = k0 / cin;
+            col = k0 - tap * cin;
+            const int dr = tap / 3 - 1, df = tap % 3 - 1;
+            const int rr = r + dr, ff = f + df;
+            row = (rr >= 0 && rr < 8 && ff >= 0 && ff < 8) ? rr * 8 + ff : zeroRow;
+        }
+        const half8 b = *reinterpret_cast<const half8*>(act + (size_t)row * lda + col);
+        acc = mfma(wfrag(w, ntilesTotal, ks, wtile, lane), b, acc);       // A = W^T fragment, B = act^T fragment
+    }
+    return acc;
+}
+
+template <int CT>      // CT = C / 64 accumulator tiles per wave
+__global__ __launch_bounds__(256) void rise_forward_kernel(NetDesc nd, const h16* __restrict__ wh, const float* __restrict__ wf,
+                                                           const h16* __restrict__ planes, int n,
+                                                           h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
+                                                           h16* __restrict__ wdl, h16* __restrict__ ml) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = nd.C;
+    const int ldx = C + 8;
+    h16* Xs = reinterpret_cast<h16*>(smem);                       // [65][ldx]   activation tile (+ zero row)
+    h16* Ss = Xs + 65 * ldx;                                      // [65][ldx]   policy trunk / input staging
+    h16* Y1 = Ss + 65 * ldx;                                      // [64][66]    expand output [ch][sq]
+    h16* Y2 = Y1 + 64 * 66;                                       // [64][72]    depthwise output [sq][ch]
+    float* Mv = reinterpret_cast<float*>(Y2 + 64 * 72);           // [C] channel means / scratch
+    float* Gv = Mv + C;                                           // [C] gates / scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
+        // ---- input planes: NCHW [74][64] fp16 -> Ss as [sq][cin_pad] (+ zero row 64)
+        const int ldi = nd.cin_pad + 8;
+        for (int i = tid; i < 65 * ldi; i += 256) Ss[i] = (h16)0.0f;
+        for (int i = tid; i < ldx; i += 256) Xs[64 * ldx + i] = (h16)0.0f;
+        __syncthreads();
+        const h16* pin = planes + (size_t)sIdx * HM_PLANE_VALUES;
+        for (int i = tid; i < HM_PLANE_VALUES; i += 256) Ss[(i & 63) * ldi + (i >> 6)] = pin[i];
+        __syncthreads();
+        // ---- stem: 3x3 conv cin -> C, + bias, ReLU
+        {
+            floatx16 acc[CT];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) acc[i] = zero16();
+            gemm_rows<CT>(acc, Ss, ldi, 64, true, nd.cin_pad, 9 * nd.cin_pad / 16, wh + nd.stem_w, C, wave, lane);
+            const float* b = wf + nd.stem_b;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const int co = ((wave >> 1) + 2 * i) * 32 + (lane & 31);
+                const float bias = b[co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int sq = (wave & 1) * 32 + drow(rg, lane);
+                    Xs[sq * ldx + co] = (h16)fmaxf(acc[i][rg] + bias, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- mobile bottleneck blocks
+        for (int bi = 0; bi < nd.nblocks; ++bi) {
+            const BlockDesc bd = nd.blk[bi];
+            if (bd.eca) {   // x = x * hardsigmoid(W_eca . mean_sq(x) + b)   (builder_util.py:49-80, centre tap)
+                for (int c = tid; c < C; c += 256) {
+                    float s = 0.0f;
+                    for (int sq = 0; sq < 64; ++sq) s += (float)Xs[sq * ldx + c];
+                    Mv[c] = s * (1.0f / 64.0f);
+                }
+                __syncthreads();
+                const h16* we = wh + bd.ecaw;                     // [ci][co]
+                for (int co = tid; co < C; co += 256) {
+                    float s = wf[bd.ecab + co];
+                    for (int ci = 0; ci < C; ++ci) s += (float)we[(size_t)ci * C + co] * Mv[ci];
+                    Gv[co] = fminf(fmaxf(s * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+                }
+                __syncthreads();
+                for (int i = tid; i < 64 * C; i += 256) {
+                    const int sq = i / C, c = i - sq * C;
+                    Xs[sq * ldx + c] = (h16)((float)Xs[sq * ldx + c] * Gv[c]);
+                }
+                __syncthreads();
+            }
+            floatx16 acc[CT];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) acc[i] = zero16();
+            const int cop = bd.cop, kk = bd.k, kh2 = kk >> 1;
+            const int copTiles = cop >> 5;
+            for (int c0 = 0; c0 < cop; c0 += 64) {
+                const int cw = cop - c0 < 64 ? cop - c0 : 64;       // 64 or 32 channels in this chunk
+                // 1x1 expand, transposed: Y1[ch][sq] = relu(W1^T x^T + b1)
+                if ((wave >> 1) * 32 < cw) {
+                    const int wt = (c0 >> 5) + (wave >> 1);
+                    floatx16 e = gemm_cols(Xs, ldx, 64, false, C, C / 16, wh + bd.w1, copTiles, wt, wave, lane);
+                    const int sq = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int ch = (wave >> 1) * 32 + drow(rg, lane);
+                        Y1[ch * 66 + sq] = (h16)fmaxf(e[rg] + wf[bd.b1 + c0 + ch], 0.0f);
+                    }
+                }
+                __syncthreads();
+                // depthwise kxk (+bias, ReLU): thread = (channel, 2 board rows); output transposed to [sq][ch]
+                {
+                    const int ch = tid & 63, g = tid >> 6;
+                    if (ch < cw) {
+                        const h16* wd = wh + bd.dw + (size_t)(c0 + ch) * kk * kk;
+                        const float bias = wf[bd.b2 + c0 + ch];
+                        float wreg[25];
+                        for (int i = 0; i < kk * kk; ++i) wreg[i] = (float)wd[i];
+                        for (int rr = 4 * 0 + 2 * g; rr < 2 * g + 2; ++rr)
+                            for (int ff = 0; ff < 8; ++ff) {
+                                float s = bias;
+                                for (int dy = -kh2; dy <= kh2; ++dy) {
+                                    const int y = rr + dy;
+                                    if (y < 0 || y > 7) continue;
+                                    for (int dx = -kh2; dx <= kh2; ++dx) {
+                                        const int x = ff + dx;
+                                        if (x < 0 || x > 7) continue;
+                                        s += wreg[(dy + kh2) * kk + dx + kh2] * (float)Y1[ch * 66 + y * 8 + x];
+                                    }
+                                }
+                                Y2[(rr * 8 + ff) * 72 + ch] = (h16)fmaxf(s, 0.0f);
+                            }
+                    }
+                }
+                __syncthreads();
+                // 1x1 project: acc[sq][co] += Y2[sq][chunk] . W2[chunk][co]
+                {
+                    const int rt = wave & 1;
+                    const int sq = rt * 32 + (lane & 31);
+                    const int ntiles = C >> 5;
+                    for (int ks = 0; ks < cw / 16; ++ks) {
+                        const half8 a = *reinterpret_cast<const half8*>(Y2 + sq * 72 + ks * 16 + 8 * (lane >> 5));
+                        const int gks = (c0 >> 4) + ks;
+#pragma unroll
+                        for (int i = 0; i < CT; ++i) {
+                            const int tile = (wave >> 1) + 2 * i;
+                            acc[i] = mfma(a, wfrag(wh + bd.w2, ntiles, gks, tile, lane), acc[i]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // residual: x = x + (acc + b3); every wave owns disjoint (sq, co) elements
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const int co = ((wave >> 1) + 2 * i) * 32 + (lane & 31);
+                const float bias = wf[bd.b3 + co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int sq = (wave & 1) * 32 + drow(rg, lane);
+                    Xs[sq * ldx + co] = (h16)((float)Xs[sq * ldx + co] + acc[i][rg] + bias);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- value head: 1x1 conv C -> cv (+bias, ReLU), NCHW flatten, linear -> (wdl x3, plys)
+        {
+            const int cv = nd.cv;                                  // <= 32
+            if (wave < 2) {                                        // one 32-channel tile, two square tiles
+                floatx16 e = gemm_cols(Xs, ldx, 64, false, C, C / 16, wh + nd.v_w, 1, 0, wave, lane);
+                const int sq = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int ch = drow(rg, lane);
+                    if (ch < cv) Y1[ch * 66 + sq] = (h16)fmaxf(e[rg] + wf[nd.v_b + ch], 0.0f);
+                }
+            }
+            __syncthreads();
+            float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const h16* wl = wh + nd.vl_w;                          // [4][cv*64], NCHW flatten order
+            for (int i = tid; i < cv * 64; i += 256) {
+                const float v = (float)Y1[(i >> 6) * 66 + (i & 63)];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] += v * (float)wl[(size_t)o * cv * 64 + i];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = part[o];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) Mv[wave * 4 + o] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float lo[4];
+                for (int o = 0; o < 4; ++o) lo[o] = Mv[o] + Mv[4 + o] + Mv[8 + o] + Mv[12 + o] + wf[nd.vl_b + o];
+                const float mx = fmaxf(lo[0], fmaxf(lo[1], lo[2]));
+                const float e0 = __expf(lo[0] - mx), e1 = __expf(lo[1] - mx), e2 = __expf(lo[2] - mx);
+                const float inv = 1.0f / (e0 + e1 + e2);
+                value[sIdx] = (h16)((e2 - e0) * inv);              // win - loss (builder_util.py:315-324)
+                wdl[(size_t)sIdx * 3 + 0] = (h16)lo[0]; wdl[(size_t)sIdx * 3 + 1] = (h16)lo[1]; wdl[(size_t)sIdx * 3 + 2] = (h16)lo[2];
+                ml[sIdx] = (h16)(1.0f / (1.0f + __expf(-lo[3])));
+            }
+        }
+        // ---- policy heads: shared 3x3 conv C -> C (+bias, ReLU) into Ss, then 3x3 C -> 146 (two boards)
+        for (int i = tid; i < ldx; i += 256) Ss[64 * ldx + i] = (h16)0.0f;
+        {
+            floatx16 acc[CT];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) acc[i] = zero16();
+            gemm_rows<CT>(acc, Xs, ldx, 64, true, C, 9 * C / 16, wh + nd.ps_w, C, wave, lane);
+            const float* b = wf + nd.ps_b;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const int co = ((wave >> 1) + 2 * i) * 32 + (lane & 31);
+                const float bias = b[co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int sq = (wave & 1) * 32 + drow(rg, lane);
+                    Ss[sq * ldx + co] = (h16)fmaxf(acc[i][rg] + bias, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // 146 output planes padded to 160 = 5 channel tiles x 2 square tiles = 10 tiles over 4 waves
+            for (int t = wave; t < 10; t += 4) {
+                const int ctile = t >> 1, stile = t & 1;
+                floatx16 e = gemm_cols(Ss, ldx, 64, true, C, 9 * C / 16, wh + nd.pp_w, 5, ctile, stile, lane);
+                const int sq = stile * 32 + (lane & 31);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int ch = ctile * 32 + drow(rg, lane);
+                    if (ch < 73) piA[(size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sq] = (h16)e[rg];
+                    else if (ch < 146) piB[(size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sq] = (h16)e[rg];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace hmn
+
+extern "C" {
+
+// desc: hmn::NetDesc as a flat int32 array (see hivemind_amd/net.py FusedNet); wh / wf: packed fp16 /
+// fp32 parameter buffers (device); planes: fp16 [n,74,8,8]; heads as in hm_sp_process.
+int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
+    using namespace hmn;
+    if (!desc || desc_ints * 4 != sizeof(NetDesc)) return hm_fail(HM_ERR_INVALID, "bad network descriptor size");
+    if (n <= 0) return 0;
+    NetDesc nd;
+    memcpy(&nd, desc, sizeof nd);
+    if (nd.C % 64 || nd.nblocks > MAXB || nd.cv > 32) return hm_fail(HM_ERR_INVALID, "unsupported network geometry");
+    const size_t ldx = nd.C + 8;
+    const size_t lds = (2 * 65 * ldx + 64 * 66 + 64 * 72) * 2 + 2 * nd.C * 4;
+    if (lds > 160 * 1024) return hm_fail(HM_ERR_INVALID, "network too wide for one LDS tile");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = n < 1024 ? n : 1024;
+    auto args = [&](auto kern) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
+                           static_cast<const h16*>(d_planes), n, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
+                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left));
+        return hipGetLastError();
+    };
+    hipError_t e;
+    switch (nd.C / 64) {
+        case 1: e = args(rise_forward_kernel<1>); break;
+        case 2: e = args(rise_forward_kernel<2>); break;
+        case 4: e = args(rise_forward_kernel<4>); break;
+        case 6: e = args(rise_forward_kernel<6>); break;
+        default: return hm_fail(HM_ERR_INVALID, "trunk width must be 64, 128, 256 or 384");
+    }
+    if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -256,3 +256,135 @@ class InferenceNet(nn.Module):
             self._graph.replay()
             return self._static_out
         return self.forward(planes)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused single-launch forward (hivemind_amd/csrc/hm_net.hip)
+# ---------------------------------------------------------------------------------------------
+def _pack_frag(wt: torch.Tensor) -> torch.Tensor:
+    """[K, N] (K % 16 == 0, N % 32 == 0) -> v_mfma_f32_32x32x16_f16 fragment order
+    [kstep][tile][lane][8]: lane l holds W[kstep*16 + 8*(l>>5) + j][tile*32 + (l&31)]."""
+    k, n = wt.shape
+    assert k % 16 == 0 and n % 32 == 0, (k, n)
+    x = wt.reshape(k // 16, 2, 8, n // 32, 32)          # ks, h, j, t, c
+    return x.permute(0, 3, 1, 4, 2).contiguous().reshape(-1)   # ks, t, h, c, j
+
+
+class FusedNet:
+    """RiseV3 (eval) -> one hm_net_forward launch per batch.  Same output contract as InferenceNet."""
+
+    MAXB, CIN_PAD = 16, 80
+
+    def __init__(self, model: RiseV3, device="cuda"):
+        import ctypes as C
+        import numpy as np
+        from ._lib import lib, check
+        import copy
+        self._C, self._lib, self._check = C, lib, check
+        model = copy.deepcopy(model).cpu().float().eval()       # packing happens on the host
+        halfs, floats = [], []
+        hoff, foff = [0], [0]
+
+        def addh(t):
+            t = t.detach().float().reshape(-1)
+            pad = (-t.numel()) % 8
+            if pad:
+                t = torch.cat([t, torch.zeros(pad)])
+            off = hoff[0]
+            halfs.append(t)
+            hoff[0] += t.numel()
+            return off
+
+        def addf(t):
+            t = t.detach().float().reshape(-1)
+            off = foff[0]
+            floats.append(t)
+            foff[0] += t.numel()
+            return off
+
+        def conv3_wt(w, cin_pad=None):          # [co][ci][3][3] -> Wt[(ky*3+kx)*cin + ci][co]
+            co, ci = w.shape[:2]
+            if cin_pad and cin_pad != ci:
+                w = torch.cat([w, torch.zeros(co, cin_pad - ci, 3, 3)], 1)
+                ci = cin_pad
+            return w.permute(2, 3, 1, 0).reshape(9 * ci, co)
+
+        def padn(wt, n):
+            return wt if wt.shape[1] == n else torch.cat([wt, torch.zeros(wt.shape[0], n - wt.shape[1])], 1)
+
+        stem = model.body_spatial[0].body
+        w, b = _fold(stem[0], stem[1])
+        ch = w.shape[0]
+        assert ch % 64 == 0
+        desc = dict(C=ch, cin_pad=self.CIN_PAD)
+        desc["stem_w"] = addh(_pack_frag(conv3_wt(w, self.CIN_PAD)))
+        desc["stem_b"] = addf(b)
+        blocks = []
+        for blk in list(model.body_spatial)[1:]:
+            body = blk.body
+            w1, b1 = _fold(body[0], body[1])
+            wd, b2 = _fold(body[3], body[4])
+            w2, b3 = _fold(body[6], body[7])
+            cop, k = w1.shape[0], wd.shape[-1]
+            assert cop % 32 == 0 and k in (3, 5)
+            d = dict(cop=cop, k=k, eca=0, ecaw=0, ecab=0)
+            d["w1"] = addh(_pack_frag(w1.reshape(cop, ch).t().contiguous()))
+            d["b1"] = addf(b1)
+            d["dw"] = addh(wd.reshape(cop, k * k))
+            d["b2"] = addf(b2)
+            d["w2"] = addh(_pack_frag(w2.reshape(ch, cop).t().contiguous()))
+            d["b3"] = addf(b3)
+            if blk.se_type:
+                c1 = blk.se.body[0]
+                kk = c1.kernel_size[0]
+                d["eca"] = 1
+                d["ecaw"] = addh(c1.weight.detach()[:, :, kk // 2].t().contiguous())     # [ci][co]
+                d["ecab"] = addf(c1.bias)
+            blocks.append(d)
+        assert len(blocks) <= self.MAXB
+        vh = model.value_head
+        wv, bv = _fold(vh.body[0], vh.body[1])
+        cv = wv.shape[0]
+        assert cv <= 32
+        desc["cv"] = cv
+        desc["v_w"] = addh(_pack_frag(padn(wv.reshape(cv, ch).t().contiguous(), 32)))
+        desc["v_b"] = addf(torch.cat([bv, torch.zeros(32 - cv)]))
+        desc["vl_w"] = addh(torch.cat([vh.body_wdl[0].weight, vh.body_plys[0].weight], 0))
+        desc["vl_b"] = addf(torch.cat([vh.body_wdl[0].bias, vh.body_plys[0].bias]))
+        ph = model.policy_heads
+        ws, bs = _fold(ph.shared_body[0], ph.shared_body[1])
+        desc["ps_w"] = addh(_pack_frag(conv3_wt(ws)))
+        desc["ps_b"] = addf(bs)
+        wp = torch.cat([ph.board_projections[0].weight.detach().float(), ph.board_projections[1].weight.detach().float()], 0)
+        desc["pp_w"] = addh(_pack_frag(padn(conv3_wt(wp), 160)))
+        ints = [desc["C"], len(blocks), desc["cv"], desc["cin_pad"], desc["stem_w"], desc["ps_w"], desc["pp_w"], desc["v_w"],
+                desc["vl_w"], desc["stem_b"], desc["ps_b"], desc["v_b"], desc["vl_b"]]
+        for i in range(self.MAXB):
+            if i < len(blocks):
+                d = blocks[i]
+                ints += [d["cop"], d["k"], d["eca"], 0, d["w1"], d["dw"], d["w2"], d["ecaw"], d["b1"], d["b2"], d["b3"], d["ecab"]]
+            else:
+                ints += [0] * 12
+        self.desc = np.asarray(ints, dtype=np.int32)
+        self.wh = torch.cat(halfs).to(device=device, dtype=torch.float16).contiguous()
+        self.wf = torch.cat(floats).to(device=device, dtype=torch.float32).contiguous()
+        self.device = self.wh.device
+        self._out = {}
+
+    def _buffers(self, n):
+        if n not in self._out:
+            f = dict(dtype=torch.float16, device=self.device)
+            self._out[n] = (torch.empty(n, **f), torch.empty((n, POLICY_CHANNELS * 64), **f), torch.empty((n, POLICY_CHANNELS * 64), **f),
+                            torch.empty((n, 3), **f), torch.empty(n, **f))
+        return self._out[n]
+
+    def __call__(self, planes: torch.Tensor):
+        if planes.dtype != torch.float16 or not planes.is_contiguous():
+            planes = planes.to(torch.float16).contiguous()
+        n = planes.shape[0]
+        v, a, b, w, m = self._buffers(n)
+        st = torch.cuda.current_stream().cuda_stream
+        self._check(self._lib.hm_net_forward(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
+                                             planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),
+                                             m.data_ptr(), self._C.c_void_p(st)))
+        return v, a, b, w, m

