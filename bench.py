@@ -163,7 +163,7 @@ def main():
         torch.manual_seed(0)
         model = N.rise_v3_small() if args.model == "small" else N.rise_v33()
         flops = N.flops_per_position(model)
-        net = N.InferenceNet(model, device=dev).capture(args.games * 8)
+        net = N.FusedNet(model, device=dev)        # single-launch HIP forward (hm_net_forward)
 
         def one_run(seed):
             cfg = hm.default_selfplay_config(games=args.games * world, nodes=args.nodes, seed=seed, concurrent_games=args.games,

@@ -63,58 +63,110 @@ __device__ __forceinline__ int drow(int reg, int lane) { return (reg & 3) + 8 * 
 //   conv3 = false: A[sq][k] = act[sq][k]                      (K = kdim)
 //   conv3 = true : A[sq][tap*cin + ci] = act[sq + shift(tap)][ci] or 0   (3x3, zero padding; K = 9*cin)
 // Wave w computes row tile (w & 1) and column tiles (w >> 1) + 2*i.  acc must hold ncol/64 tiles.
+// im2col / plain row address of the A (or transposed B) fragment of k-step `ks` for square `sq`
+__device__ __forceinline__ const h16* frag_src(const h16* act, int lda, int zeroRow, bool conv3, int cin, int ks, int kh, int sq) {
+    const int k0 = ks * 16 + kh;
+    int row = sq, col = k0;
+    if (conv3) {
+        const int tap = k0 / cin;
+        col = k0 - tap * cin;
+        const int dr = tap / 3 - 1, df = tap % 3 - 1;
+        const int rr = (sq >> 3) + dr, ff = (sq & 7) + df;
+        row = (rr >= 0 && rr < 8 && ff >= 0 && ff < 8) ? rr * 8 + ff : zeroRow;
+    }
+    return act + (size_t)row * lda + col;
+}
+
+// k-steps are processed in groups of KG: all weight-fragment loads of a group (KG x tiles, 1 KiB each
+// per wave) are issued before the first MFMA of the group, so their L2 latency overlaps instead of
+// serialising one load per MFMA.
 template <int MAXT>
 __device__ __forceinline__ void gemm_rows(floatx16 (&acc)[MAXT], const h16* act, int lda, int zeroRow, bool conv3, int cin,
                                           int ksteps, const h16* w, int ncol, int wave, int lane) {
+    constexpr int KG = MAXT <= 2 ? 4 : 2;
     const int ntiles = ncol >> 5;
-    const int rt = wave & 1;
-    const int sq = rt * 32 + (lane & 31);
-    const int f = sq & 7, r = sq >> 3;
+    const int sq = (wave & 1) * 32 + (lane & 31);
     const int kh = 8 * (lane >> 5);
-    const int nt = ntiles >> 1;                       // tiles per wave
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int k0 = ks * 16 + kh;
-        int row = sq, col = k0;
-        if (conv3) {
-            const int tap = k0 / cin;
-            col = k0 - tap * cin;
-            const int dr = tap / 3 - 1, df = tap % 3 - 1;
-            const int rr = r + dr, ff = f + df;
-            row = (rr >= 0 && rr < 8 && ff >= 0 && ff < 8) ? rr * 8 + ff : zeroRow;
-        }
-        const half8 a = *reinterpret_cast<const half8*>(act + (size_t)row * lda + col);
+    const int t0 = wave >> 1;
+    int ks = 0;
+    for (; ks + KG <= ksteps; ks += KG) {
+        half8 a[KG], b[KG][MAXT];
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i) {
-            if (i < nt) {
-                const int tile = (wave >> 1) + 2 * i;
-                acc[i] = mfma(a, wfrag(w, ntiles, ks, tile, lane), acc[i]);
-            }
+        for (int u = 0; u < KG; ++u) {
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) b[u][i] = wfrag(w, ntiles, ks + u, t0 + 2 * i, lane);
         }
+#pragma unroll
+        for (int u = 0; u < KG; ++u) a[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
+#pragma unroll
+        for (int u = 0; u < KG; ++u) {
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) acc[i] = mfma(a[u], b[u][i], acc[i]);
+        }
+    }
+    for (; ks < ksteps; ++ks) {
+        const half8 a = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks, kh, sq));
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) acc[i] = mfma(a, wfrag(w, ntiles, ks, t0 + 2 * i, lane), acc[i]);
     }
 }
 
-// Transposed GEMM: D[ch][sq] = sum_k W[k][ch] * act[sq][k]; 64 (or 32) output channels x 64 squares,
-// one 32x32 tile per wave (ch tile = wave >> 1, sq tile = wave & 1).  `wtile0` = first channel tile.
+// Transposed GEMM: D[ch][sq] = sum_k W[k][ch] * act[sq][k]; one 32x32 tile per call
+// (channel tile `wtile` of the packed matrix, square tile = wave & 1).
 __device__ __forceinline__ floatx16 gemm_cols(const h16* act, int lda, int zeroRow, bool conv3, int cin, int ksteps,
                                               const h16* w, int ntilesTotal, int wtile, int wave, int lane) {
+    constexpr int KG = 8;
     floatx16 acc = zero16();
     const int sq = (wave & 1) * 32 + (lane & 31);
-    const int f = sq & 7, r = sq >> 3;
     const int kh = 8 * (lane >> 5);
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int k0 = ks * 16 + kh;
-        int row = sq, col = k0;
-        if (conv3) {
-            const int tap = k0 / cin;
-            col = k0 - tap * cin;
-            const int dr = tap / 3 - 1, df = tap % 3 - 1;
-            const int rr = r + dr, ff = f + df;
-            row = (rr >= 0 && rr < 8 && ff >= 0 && ff < 8) ? rr * 8 + ff : zeroRow;
-        }
-        const half8 b = *reinterpret_cast<const half8*>(act + (size_t)row * lda + col);
-        acc = mfma(wfrag(w, ntilesTotal, ks, wtile, lane), b, acc);       // A = W^T fragment, B = act^T fragment
+    int ks = 0;
+    for (; ks + KG <= ksteps; ks += KG) {
+        half8 a[KG], b[KG];
+#pragma unroll
+        for (int u = 0; u < KG; ++u) a[u] = wfrag(w, ntilesTotal, ks + u, wtile, lane);
+#pragma unroll
+        for (int u = 0; u < KG; ++u) b[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
+#pragma unroll
+        for (int u = 0; u < KG; ++u) acc = mfma(a[u], b[u], acc);       // A = W^T fragment, B = act^T fragment
+    }
+    for (; ks < ksteps; ++ks) {
+        const half8 b = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks, kh, sq));
+        acc = mfma(wfrag(w, ntilesTotal, ks, wtile, lane), b, acc);
     }
     return acc;
+}
+
+// depthwise KxK (+bias, ReLU) for one channel and two board rows; weights in registers
+template <int K>
+__device__ __forceinline__ void depthwise_rows(const h16* y1 /*[66] row of this channel*/, h16* y2, int ch, int g, const h16* wd, float bias) {
+    constexpr int H = K / 2;
+    float wreg[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wreg[i] = (float)wd[i];
+    // the K+1 input rows this thread needs, zero padded in both directions
+    float in[K + 1][8 + 2 * H];
+#pragma unroll
+    for (int r = 0; r < K + 1; ++r) {
+        const int y = 2 * g - H + r;
+#pragma unroll
+        for (int x = 0; x < 8 + 2 * H; ++x) {
+            const int xx = x - H;
+            in[r][x] = (y >= 0 && y < 8 && xx >= 0 && xx < 8) ? (float)y1[y * 8 + xx] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int ff = 0; ff < 8; ++ff) {
+            float s = bias;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) s += wreg[dy * K + dx] * in[o + dy][ff + dx];
+            }
+            y2[((2 * g + o) * 8 + ff) * 72 + ch] = (h16)fmaxf(s, 0.0f);
+        }
+    }
 }
 
 template <int CT>      // CT = C / 64 accumulator tiles per wave
@@ -187,7 +239,7 @@ __global__ __launch_bounds__(256) void rise_forward_kernel(NetDesc nd, const h16
             floatx16 acc[CT];
 #pragma unroll
             for (int i = 0; i < CT; ++i) acc[i] = zero16();
-            const int cop = bd.cop, kk = bd.k, kh2 = kk >> 1;
+            const int cop = bd.cop, kk = bd.k;
             const int copTiles = cop >> 5;
             for (int c0 = 0; c0 < cop; c0 += 64) {
                 const int cw = cop - c0 < 64 ? cop - c0 : 64;       // 64 or 32 channels in this chunk
@@ -209,40 +261,14 @@ __global__ __launch_bounds__(256) void rise_forward_kernel(NetDesc nd, const h16
                     if (ch < cw) {
                         const h16* wd = wh + bd.dw + (size_t)(c0 + ch) * kk * kk;
                         const float bias = wf[bd.b2 + c0 + ch];
-                        float wreg[25];
-                        for (int i = 0; i < kk * kk; ++i) wreg[i] = (float)wd[i];
-                        for (int rr = 4 * 0 + 2 * g; rr < 2 * g + 2; ++rr)
-                            for (int ff = 0; ff < 8; ++ff) {
-                                float s = bias;
-                                for (int dy = -kh2; dy <= kh2; ++dy) {
-                                    const int y = rr + dy;
-                                    if (y < 0 || y > 7) continue;
-                                    for (int dx = -kh2; dx <= kh2; ++dx) {
-                                        const int x = ff + dx;
-                                        if (x < 0 || x > 7) continue;
-                                        s += wreg[(dy + kh2) * kk + dx + kh2] * (float)Y1[ch * 66 + y * 8 + x];
-                                    }
-                                }
-                                Y2[(rr * 8 + ff) * 72 + ch] = (h16)fmaxf(s, 0.0f);
-                            }
+                        if (kk == 3) depthwise_rows<3>(Y1 + ch * 66, Y2, ch, g, wd, bias);
+                        else depthwise_rows<5>(Y1 + ch * 66, Y2, ch, g, wd, bias);
                     }
                 }
                 __syncthreads();
                 // 1x1 project: acc[sq][co] += Y2[sq][chunk] . W2[chunk][co]
-                {
-                    const int rt = wave & 1;
-                    const int sq = rt * 32 + (lane & 31);
-                    const int ntiles = C >> 5;
-                    for (int ks = 0; ks < cw / 16; ++ks) {
-                        const half8 a = *reinterpret_cast<const half8*>(Y2 + sq * 72 + ks * 16 + 8 * (lane >> 5));
-                        const int gks = (c0 >> 4) + ks;
-#pragma unroll
-                        for (int i = 0; i < CT; ++i) {
-                            const int tile = (wave >> 1) + 2 * i;
-                            acc[i] = mfma(a, wfrag(wh + bd.w2, ntiles, gks, tile, lane), acc[i]);
-                        }
-                    }
-                }
+                if (cw == 64) gemm_rows<CT>(acc, Y2, 72, 0, false, 64, 4, wh + bd.w2 + (size_t)(c0 >> 4) * (C >> 5) * 512, C, wave, lane);
+                else          gemm_rows<CT>(acc, Y2, 72, 0, false, 64, 2, wh + bd.w2 + (size_t)(c0 >> 4) * (C >> 5) * 512, C, wave, lane);
                 __syncthreads();
             }
             // residual: x = x + (acc + b3); every wave owns disjoint (sq, co) elements

@@ -378,11 +378,12 @@ class FusedNet:
                             torch.empty((n, 3), **f), torch.empty(n, **f))
         return self._out[n]
 
-    def __call__(self, planes: torch.Tensor):
+    def __call__(self, planes: torch.Tensor, out=None):
+        """out = (value[n], pi_a[n,4672], pi_b[n,4672], wdl[n,3], moves_left[n]) fp16 tensors to fill in place."""
         if planes.dtype != torch.float16 or not planes.is_contiguous():
             planes = planes.to(torch.float16).contiguous()
         n = planes.shape[0]
-        v, a, b, w, m = self._buffers(n)
+        v, a, b, w, m = out if out is not None else self._buffers(n)
         st = torch.cuda.current_stream().cuda_stream
         self._check(self._lib.hm_net_forward(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
                                              planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),

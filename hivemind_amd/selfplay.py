@@ -85,8 +85,15 @@ class SelfPlay:
         self.eval_rows = 0
         self._error = None
 
+        fused = hasattr(self.net, "wh")            # FusedNet: writes the registered head buffers directly
+
         def cb(_user, which, rows_):
             try:
+                if fused:
+                    self.net(self.planes[which][:rows_], out=(self.value[:rows_], self.pi_a[:rows_], self.pi_b[:rows_],
+                                                               self.wdl[:rows_], self.ml[:rows_]))
+                    self.eval_rows += rows_
+                    return 0
                 with torch.no_grad():
                     v, a, b, w, m = self.net(self.planes[which][:rows_])
                 self.value[:rows_].copy_(v.reshape(-1)); self.pi_a[:rows_].copy_(a); self.pi_b[:rows_].copy_(b)

@@ -15,13 +15,17 @@ ap.add_argument("--model", default="small", choices=["small", "full"])
 ap.add_argument("--max-macro-plies", type=int, default=400)
 ap.add_argument("--out", default="gpurun_out/selfplay")
 ap.add_argument("--graph", action="store_true")
+ap.add_argument("--torch-net", action="store_true", help="library (MIOpen) path instead of the fused HIP forward")
 a = ap.parse_args()
 hm.init(0)
 torch.manual_seed(0)
 model = N.rise_v3_small() if a.model == "small" else N.rise_v33()
-net = N.InferenceNet(model)
-if a.graph:
-    net.capture(a.concurrent * 8)
+if a.torch_net:
+    net = N.InferenceNet(model)
+    if a.graph:
+        net.capture(a.concurrent * 8)
+else:
+    net = N.FusedNet(model)
 cfg = hm.default_selfplay_config(games=a.games, nodes=a.nodes, seed=a.seed, concurrent_games=a.concurrent, max_macro_plies=a.max_macro_plies)
 sp = hm.SelfPlay(cfg, net)
 t = time.time()
