@@ -148,7 +148,31 @@ __device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, con
     return true;
 }
 
-// board.cc:169-208.  scratch: 2 lists.
+// Legal move counts of both boards, computed by lanes 0 and 1 concurrently (wave-uniform call).
+__device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, int& cntB) {
+    const int lane = threadIdx.x & 63;
+    int c = 0;
+    if (lane < 2) c = count_legal(t.att, bd[lane]);
+    cntA = __shfl(c, 0); cntB = __shfl(c, 1);
+}
+
+// board.cc:169-208 with the per-board MoveList<LEGAL>::size() values supplied.  scratch: 2 lists.
+__device__ inline bool is_checkmate_c(const RulesTab& t, const P* bd, int side, bool adv, int cntA, int cntB, u32* scratch) {
+    const bool onA = (int)bd[0].stm == side, onB = (int)bd[1].stm == (side ^ 1);
+    if (onA) {
+        if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd, 0, side, adv, scratch)) return true;
+    }
+    if (onB) {
+        if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd, 1, side ^ 1, adv, scratch)) return true;
+    }
+    if (onA || onB) {
+        const bool movesA = onA && cntA > 0, movesB = onB && cntB > 0;
+        if (!movesA && !movesB && (!adv || (onA && onB))) return true;
+    }
+    return false;
+}
+
+// board.cc:169-208.  scratch: 2 lists.  Safe in lane-divergent code (no cross-lane operations).
 __device__ inline bool is_checkmate(const RulesTab& t, const P* bd, int side, bool adv, u32* scratch) {
     const bool onA = (int)bd[0].stm == side, onB = (int)bd[1].stm == (side ^ 1);
     int cntA = -1, cntB = -1;
@@ -197,18 +221,39 @@ __device__ inline void jb_make(const RulesTab& t, JBoard& j, u32 ma, u32 mb, boo
     if (mb) jb_push(t, j, 1, mb, writer);
 }
 
-// searchthread.cc:21-39; returns number of mating moves written to `out`.  scratch: 3 lists.
+// searchthread.cc:21-39; returns number of mating moves written to `out` (wave-uniform call).
+// scratch: 3 lists.  Lanes test the moves in parallel for "gives check and leaves the victim a board
+// without legal moves" (necessary for Board::is_checkmate); survivors are verified in list order.
 __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& j, int b, int victimTeam, bool victimAdv, u32* out, u32* scratch) {
+    const int lane = threadIdx.x & 63;
     u32* list = scratch;
-    const int n = gen_legal(t.att, j.bd[b], list);
+    int n = 0;
+    if (lane == 0) n = gen_legal(t.att, j.bd[b], list);
+    n = __shfl(n, 0);
+    __builtin_amdgcn_wave_barrier();
     int k = 0;
-    for (int i = 0; i < n; ++i) {
-        const u32 m = list[i];
-        P nb[2] = {j.bd[0], j.bd[1]};
-        const int h = do_move(t.att, t.zob, nb[b], m);
-        if (!checkers_of(t.att, nb[b])) continue;            // gives_check
-        if (h) add_to_hand(t.zob, nb[1 - b], h);
-        if (is_checkmate(t, nb, victimTeam, victimAdv, scratch + HM_MAX_MOVES)) out[k++] = m;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool cand = false;
+        if (i < n) {
+            P nb[2] = {j.bd[0], j.bd[1]};
+            const int h = do_move(t.att, t.zob, nb[b], list[i]);
+            if (checkers_of(t.att, nb[b])) {
+                if (h) add_to_hand(t.zob, nb[1 - b], h);
+                const bool vA = (int)nb[0].stm == victimTeam, vB = (int)nb[1].stm == (victimTeam ^ 1);
+                cand = (vA && count_legal(t.att, nb[0]) == 0) || (vB && count_legal(t.att, nb[1]) == 0);
+            }
+        }
+        u64 mask = __ballot(cand);
+        while (mask) {
+            const int q = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const u32 m = list[base + q];
+            P nb[2] = {j.bd[0], j.bd[1]};
+            const int h = do_move(t.att, t.zob, nb[b], m);
+            if (h) add_to_hand(t.zob, nb[1 - b], h);
+            if (is_checkmate(t, nb, victimTeam, victimAdv, scratch + HM_MAX_MOVES)) out[k++] = m;
+        }
     }
     return k;
 }
@@ -271,8 +316,10 @@ __device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, con
 __device__ inline int classify_terminal_position(const RulesTab& t, const JBoard& j, int teamToPlay, int rootTeam, bool rootAdv, int searchPly, int* endInPly, u32* scratch) {
     *endInPly = 0;
     const bool adv = teamToPlay == rootTeam ? rootAdv : !rootAdv;
-    if (is_checkmate(t, j.bd, teamToPlay ^ 1, !adv, scratch)) { *endInPly = 1; return 1; }
-    if (is_checkmate(t, j.bd, teamToPlay, adv, scratch)) { *endInPly = 1; return 2; }
+    int cntA, cntB;
+    legal_counts(t, j.bd, cntA, cntB);               // each board's count serves exactly one of the two tests
+    if (is_checkmate_c(t, j.bd, teamToPlay ^ 1, !adv, cntA, cntB, scratch)) { *endInPly = 1; return 1; }
+    if (is_checkmate_c(t, j.bd, teamToPlay, adv, cntA, cntB, scratch)) { *endInPly = 1; return 2; }
     if (jb_is_draw(j, searchPly)) return 3;
     if (searchPly > 0 && has_unavoidable_waiting_board_mate(t, j, teamToPlay, adv, searchPly, scratch)) { *endInPly = 3; return 2; }
     return 0;

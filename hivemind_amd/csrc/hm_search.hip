@@ -101,7 +101,7 @@ struct Game {
     int team, adv;
     // search state
     int status, root, nodeCount, nodesSearched, targetNodes, pending;
-    u32 arenaTop;
+    unsigned int arenaTop;
     int ctxCount[2], validCount[2];
     float alpha, eps;
     u64 noiseSeed, rootHash;
@@ -199,17 +199,20 @@ __device__ __forceinline__ Edge* edges_of(const G& s, const Node& n) { return re
 __device__ __forceinline__ GenHdr* gen_of(const G& s, const Node& n) { return reinterpret_cast<GenHdr*>(s.arena + n.gen); }
 
 // bump allocation in 8-byte units; offset 0 is reserved as "null"
+// (lane 0 bumps the counter atomically and broadcasts: several waves of a block may allocate at once)
 __device__ inline u32 arena_alloc(G& s, u32 bytes) {
     const u32 units = (bytes + 7) >> 3;
-    const u32 top = s.g->arenaTop;
-    if (top + units > s.prm->arenaCap) { s.g->overflow |= 1; return 0; }
-    s.g->arenaTop = top + units;
+    u32 top = 0;
+    if ((threadIdx.x & 63) == 0) top = atomicAdd(&s.g->arenaTop, units);
+    top = __shfl(top, 0);
+    if (top + units > s.prm->arenaCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 1); return 0; }
     return top;
 }
 __device__ inline int node_alloc(G& s, int team, int depth) {
-    const int id = s.g->nodeCount;
-    if (id >= s.prm->nodeCap) { s.g->overflow |= 2; return -1; }
-    s.g->nodeCount = id + 1;
+    int id = 0;
+    if ((threadIdx.x & 63) == 0) id = atomicAdd(&s.g->nodeCount, 1);
+    id = __shfl(id, 0);
+    if (id >= s.prm->nodeCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 2); return -1; }
     Node n;
     n.hash = 0; n.valueSum = 0.0f; n.visits = 0; n.vvsum = 0; n.expanded = 0; n.endInPly = 0; n.unsolved = 0; n.cntTypes = 0;
     n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.pad = 0; n.pad2 = 0;
@@ -686,9 +689,13 @@ __device__ inline void write_planes_f16(const RulesTab& rt, const u64* bw /*26 w
     __builtin_amdgcn_wave_barrier();
 }
 
+struct ExpLds {          // per-wave scratch of expand_leaf
+    u32 lists[2][HM_MAX_MOVES];
+    float priors[2][HM_MAX_MOVES + 8];
+};
 struct WaveLds {
     u32 lists[NLISTS][HM_MAX_MOVES];
-    float priors[2][HM_MAX_MOVES + 8];
+    ExpLds exp;
     u64 board[26];
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
@@ -716,7 +723,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
 // process of one context list (searchthread.cc:444-639).  outs == nullptr for terminal-only batches.
 struct NetOut { const uint16_t *value, *piA, *piB, *wdl, *ml; };
 
-__device__ inline void expand_leaf(G& s, const RulesTab& rt, WaveLds& L, const Ctx& ctx, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
+__device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
     const int lane = threadIdx.x & 63;
     P bd[2];
     load_pos(bd[0], &ctx.pos[0]);
@@ -882,7 +889,24 @@ __device__ inline float shape_value(const G& s, uint16_t valueH, const uint16_t*
     return clampf(nv, -1.0f, 1.0f);
 }
 
-__device__ inline void process_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+// process_batch (searchthread.cc:444-639) split for the GPU: the leaf expansions of a batch are
+// independent (distinct, reserved leaves) and run one per wave; value shaping + backup then run
+// sequentially in context order on wave 0 (float sums and solver propagation are order dependent).
+__device__ inline int ctx_row(const G& s, int buf, int i) {   // inference row of context i (non-terminal contexts in order)
+    int inf = 0;
+    for (int k = 0; k < i; ++k) inf += s.ctx[buf * BATCH + k].terminal ? 0 : 1;
+    return inf;
+}
+__device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+    const Ctx& ctx = s.ctx[buf * BATCH + i];
+    if (ctx.terminal) return;
+    if (s.nodes[ctx.leaf].type != T_UNSOLVED) return;
+    const int row = rowBase + ctx_row(s, buf, i);
+    if (ctx.leafHash != 0) s.nodes[ctx.leaf].hash = ctx.leafHash;
+    if (!(s.nodes[ctx.leaf].flags & F_EXPANDED))
+        expand_leaf(s, rt, L, ctx, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
+}
+__device__ inline void backup_batch(G& s, int buf, const NetOut* out, int rowBase) {
     const int n = s.g->ctxCount[buf];
     int inf = 0;
     for (int i = 0; i < n; ++i) {
@@ -893,17 +917,10 @@ __device__ inline void process_batch(G& s, const RulesTab& rt, WaveLds& L, int b
             backup(s, tr, ctx.trajLen, ctx.termValue);
             continue;
         }
-        if (s.nodes[ctx.leaf].type != T_UNSOLVED) {
-            s.nodes[ctx.leaf].flags &= ~F_PENDING;
-            backup(s, tr, ctx.trajLen, 0.0f);
-            inf++;
-            continue;
-        }
-        const int row = rowBase + inf;
-        if (ctx.leafHash != 0) s.nodes[ctx.leaf].hash = ctx.leafHash;
-        if (!(s.nodes[ctx.leaf].flags & F_EXPANDED))
-            expand_leaf(s, rt, L, ctx, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
+        const uint8_t typeBefore = s.nodes[ctx.leaf].type;
         s.nodes[ctx.leaf].flags &= ~F_PENDING;
+        if (typeBefore != T_UNSOLVED) { backup(s, tr, ctx.trajLen, 0.0f); inf++; continue; }
+        const int row = rowBase + inf;
         const float nv = shape_value(s, out->value[row], out->wdl + (size_t)row * 3, out->ml[row]);
         backup(s, tr, ctx.trajLen, nv);
         inf++;
@@ -911,6 +928,13 @@ __device__ inline void process_batch(G& s, const RulesTab& rt, WaveLds& L, int b
     s.g->nodesSearched += n;
     s.g->ctxCount[buf] = 0;
     s.g->validCount[buf] = 0;
+}
+// single-wave form (used where only one wave runs: terminal-only batches inside k_collect)
+__device__ inline void process_batch(G& s, const RulesTab& rt, ExpLds& L, int buf, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+    const int n = s.g->ctxCount[buf];
+    if (out) for (int i = 0; i < n; ++i) expand_context(s, rt, L, buf, i, rootTeam, rootAdv, out, rowBase);
+    wave_fence();
+    backup_batch(s, buf, out, rowBase);
 }
 __device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
     const int n = s.g->ctxCount[buf];
@@ -1032,7 +1056,7 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
         if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
         collect_batch(s, s_rt, L, 0, rootTeam, rootAdv, cur);
         if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return; }   // no progress possible
-        if (s.g->validCount[0] == 0) { process_batch(s, s_rt, L, 0, rootTeam, rootAdv, nullptr, 0); continue; }
+        if (s.g->validCount[0] == 0) { process_batch(s, s_rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
         s.g->pending = 0;
         collect_batch(s, s_rt, L, 1, rootTeam, rootAdv, nxt);
         return;
@@ -1041,34 +1065,42 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
     collect_batch(s, s_rt, L, 1 - s.g->pending, rootTeam, rootAdv, nxt);
 }
 
-__global__ __launch_bounds__(64) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
+__global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
     __shared__ RulesTab s_rt;
-    __shared__ WaveLds L;
+    __shared__ ExpLds s_exp[BATCH];
     stage_table(&s_rt, pl.rules);
     __syncthreads();
-    const int g = blockIdx.x;
+    const int g = blockIdx.x, wave = threadIdx.x >> 6;
     G s = make_view(pl, prm, g);
     const int st = s.g->status;
-    if (st != ST_SEARCHING && st != ST_FINISHING) return;
+    if (st != ST_SEARCHING && st != ST_FINISHING) return;      // uniform across the block
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
     const int rowBase = g * BATCH;
+    const int pending = s.g->pending;
+    const bool solvedOrOverflow = s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow;
+    const bool doProcess = pending >= 0 && !(st == ST_FINISHING && solvedOrOverflow);
+    // phase A: one leaf expansion per wave
+    if (doProcess && wave < s.g->ctxCount[pending]) expand_context(s, s_rt, s_exp[wave], pending, wave, rootTeam, rootAdv, &out, rowBase);
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+    // phase B (wave 0): ordered backups and the run_iteration / finish_pending tail
     if (st == ST_FINISHING) {
         // finish_pending_iteration / discard_pending_iteration (agent.cc:343-352)
-        if (s.g->pending >= 0) {
-            const int done = s.g->pending;
+        if (pending >= 0) {
             s.g->pending = -1;
-            if (s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) abort_batch(s, done);
-            else process_batch(s, s_rt, L, done, rootTeam, rootAdv, &out, rowBase);
+            if (solvedOrOverflow) abort_batch(s, pending);
+            else backup_batch(s, pending, &out, rowBase);
         }
         s.g->status = s.g->overflow ? ST_ERROR : ST_DONE;
         return;
     }
-    if (s.g->pending < 0) { if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1); return; }
-    const int done = s.g->pending, look = 1 - done;
+    if (pending < 0) { if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1); return; }
+    const int look = 1 - pending;
     s.g->pending = -1;
-    process_batch(s, s_rt, L, done, rootTeam, rootAdv, &out, rowBase);
-    if (s.g->validCount[look] == 0) process_batch(s, s_rt, L, look, rootTeam, rootAdv, nullptr, 0);
+    backup_batch(s, pending, &out, rowBase);
+    if (s.g->validCount[look] == 0) process_batch(s, s_rt, s_exp[0], look, rootTeam, rootAdv, nullptr, 0);
     else s.g->pending = look;
     if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
 }
@@ -1335,7 +1367,7 @@ __global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const u
     const bool on[2] = {(int)bd[0].stm == team, (int)bd[1].stm == (team ^ 1)};
     for (int b = 0; b < 2; ++b) {
         u32* list = L.lists[b];
-        float* pr = L.priors[b];
+        float* pr = L.exp.priors[b];
         int n = 0;
         if (on[b]) {
             n = gen_legal(s_rt.att, bd[b], list);
@@ -1652,7 +1684,7 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
     HIPCHK(hipMemsetAsync(sp->d_active, 0, sizeof(int), st));
     NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
              static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
-    hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64), 0, st, sp->pl, sp->prm, o, sp->d_active);
+    hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64 * BATCH), 0, st, sp->pl, sp->prm, o, sp->d_active);
     HIPCHK(hipGetLastError());
     if (active_games) {
         HIPCHK(hipMemcpyAsync(active_games, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, st));
