@@ -169,12 +169,13 @@ __device__ __forceinline__ void depthwise_rows(const h16* y1 /*[66] row of this 
     }
 }
 
-template <int CT>      // CT = C / 64 accumulator tiles per wave
-__global__ __launch_bounds__(256) void rise_forward_kernel(NetDesc nd, const h16* __restrict__ wh, const float* __restrict__ wf,
+template <int CT, bool K5>      // CT = C / 64 accumulator tiles per wave; K5 = some block uses a 5x5 depthwise
+__global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
                                                            const h16* __restrict__ planes, int n,
                                                            h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
                                                            h16* __restrict__ wdl, h16* __restrict__ ml) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const NetDesc& nd = *ndp;                 // descriptor stays in (scalar-loadable) global memory
     const int C = nd.C;
     const int ldx = C + 8;
     h16* Xs = reinterpret_cast<h16*>(smem);                       // [65][ldx]   activation tile (+ zero row)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void rise_forward_kernel(NetDesc nd, const h16
                     if (ch < cw) {
                         const h16* wd = wh + bd.dw + (size_t)(c0 + ch) * kk * kk;
                         const float bias = wf[bd.b2 + c0 + ch];
-                        if (kk == 3) depthwise_rows<3>(Y1 + ch * 66, Y2, ch, g, wd, bias);
+                        if (!K5 || kk == 3) depthwise_rows<3>(Y1 + ch * 66, Y2, ch, g, wd, bias);
                         else depthwise_rows<5>(Y1 + ch * 66, Y2, ch, g, wd, bias);
                     }
                 }
@@ -378,21 +379,40 @@ int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, cons
     const size_t lds = (2 * 65 * ldx + 64 * 66 + 64 * 72) * 2 + 2 * nd.C * 4;
     if (lds > 160 * 1024) return hm_fail(HM_ERR_INVALID, "network too wide for one LDS tile");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // device copies of the descriptor: a small ring, re-uploaded (stream-ordered) only when the content changes
+    static NetDesc* d_ring = nullptr;
+    static NetDesc h_ring[8];
+    static int ring_used = 0;
+    if (!d_ring && hipMalloc(&d_ring, sizeof(NetDesc) * 8) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed");
+    int slot = -1;
+    for (int i = 0; i < ring_used; ++i) if (!memcmp(&h_ring[i], &nd, sizeof nd)) { slot = i; break; }
+    if (slot < 0) {
+        if (ring_used == 8) return hm_fail(HM_ERR_OVERFLOW, "more than 8 distinct networks in one process");
+        slot = ring_used++;
+        h_ring[slot] = nd;
+        if (hipMemcpy(d_ring + slot, &nd, sizeof nd, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "descriptor upload failed");
+    }
+    const NetDesc* d_nd = d_ring + slot;
     const int grid = n < 1024 ? n : 1024;
     auto args = [&](auto kern) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
                            static_cast<const h16*>(d_planes), n, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
                            static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left));
         return hipGetLastError();
     };
+    bool k5 = false;
+    for (int i = 0; i < nd.nblocks; ++i) {
+        if (nd.blk[i].k != 3 && nd.blk[i].k != 5) return hm_fail(HM_ERR_INVALID, "depthwise kernel must be 3 or 5");
+        k5 |= nd.blk[i].k == 5;
+    }
     hipError_t e;
     switch (nd.C / 64) {
-        case 1: e = args(rise_forward_kernel<1>); break;
-        case 2: e = args(rise_forward_kernel<2>); break;
-        case 4: e = args(rise_forward_kernel<4>); break;
-        case 6: e = args(rise_forward_kernel<6>); break;
+        case 1: e = k5 ? args(rise_forward_kernel<1, true>) : args(rise_forward_kernel<1, false>); break;
+        case 2: e = k5 ? args(rise_forward_kernel<2, true>) : args(rise_forward_kernel<2, false>); break;
+        case 4: e = k5 ? args(rise_forward_kernel<4, true>) : args(rise_forward_kernel<4, false>); break;
+        case 6: e = k5 ? args(rise_forward_kernel<6, true>) : args(rise_forward_kernel<6, false>); break;
         default: return hm_fail(HM_ERR_INVALID, "trunk width must be 64, 128, 256 or 384");
     }
     if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));

@@ -107,6 +107,7 @@ struct Game {
     u64 noiseSeed, rootHash;
     int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
     int nodesVisited, edgesScanned;     // traversal traffic counters (roofline accounting)
+    int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
 };
 
 struct Params {          // device-visible configuration + pool geometry
@@ -1039,7 +1040,13 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
 // =======================================================================================
 // kernels (one wave / block of 64 threads per game)
 // =======================================================================================
-__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesCur, uint16_t* planesNext) {
+// One lockstep iteration, collect side.  The kernel only ever writes the NEXT plane tensor, so it
+// is independent of the network launch that reads CUR and the two overlap on separate streams
+// (the reference overlaps collect_batch with the in-flight TensorRT batch the same way,
+// searchthread.cc:680-688).  A game with no batch in flight collects its first batch into NEXT and
+// marks it `fresh`; its lookahead follows one iteration later (same order of tree operations as
+// run_iteration: collect b0, collect b1, process b0).
+__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext) {
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     stage_table(&s_rt, pl.rules);
@@ -1049,16 +1056,15 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
     if (s.g->status != ST_SEARCHING) return;
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
-    uint16_t* cur = planesCur + (size_t)g * BATCH * HM_PLANE_VALUES;
     uint16_t* nxt = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
     // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
     while (s.g->pending < 0) {
         if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
-        collect_batch(s, s_rt, L, 0, rootTeam, rootAdv, cur);
+        collect_batch(s, s_rt, L, 0, rootTeam, rootAdv, nxt);
         if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return; }   // no progress possible
         if (s.g->validCount[0] == 0) { process_batch(s, s_rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
         s.g->pending = 0;
-        collect_batch(s, s_rt, L, 1, rootTeam, rootAdv, nxt);
+        s.g->fresh = 1;
         return;
     }
     if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
@@ -1077,6 +1083,11 @@ __global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, Ne
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
     const int rowBase = g * BATCH;
+    if (st == ST_SEARCHING && s.g->fresh) {                    // first batch of this game is still waiting for its evaluation
+        __syncthreads();
+        if (threadIdx.x == 0) { s.g->fresh = 0; atomicAdd(activeCount, 1); }
+        return;
+    }
     const int pending = s.g->pending;
     const bool solvedOrOverflow = s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow;
     const bool doProcess = pending >= 0 && !(st == ST_FINISHING && solvedOrOverflow);
@@ -1121,7 +1132,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     gm.nodeCount = 0; gm.arenaTop = 1; gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
     gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
     gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
-    gm.nodesVisited = gm.edgesScanned = 0;
+    gm.nodesVisited = gm.edgesScanned = 0; gm.fresh = 0;
     gm.targetNodes = targetNodes[g]; gm.noiseSeed = noiseSeeds ? noiseSeeds[g] : 0; gm.alpha = alpha; gm.eps = eps;
     gm.root = -1;
     Path p;
@@ -1474,6 +1485,9 @@ __global__ __launch_bounds__(64) void k_rules_probe(const RulesTab* rules, const
 
 }  // namespace hms
 
+struct hm_sp;
+extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -1669,10 +1683,10 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
     return 0;
 }
 
-int hm_sp_collect(hm_sp* sp, void* d_planes_cur, void* d_planes_next, void* stream) {
-    if (!sp || !d_planes_cur || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
+int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream) {
+    if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
-                       static_cast<uint16_t*>(d_planes_cur), static_cast<uint16_t*>(d_planes_next));
+                       static_cast<uint16_t*>(d_planes_next));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1710,6 +1724,11 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream) {
+    HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
 // number of games still searching after the last hm_sp_process (synchronises the null stream)
 int hm_sp_active(hm_sp* sp, int* active) {
     if (!sp || !active) return hm_fail(HM_ERR_INVALID, "null argument");

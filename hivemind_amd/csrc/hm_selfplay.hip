@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -32,6 +33,7 @@
 
 int hm_fail(int code, const std::string& msg);
 extern "C" int hm_sp_active(hm_sp* sp, int* active);
+extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
 
 namespace {
 
@@ -110,7 +112,9 @@ struct hm_selfplay {
     hm_board* d_boards = nullptr;
     uint8_t* d_u8 = nullptr;
     std::vector<uint64_t> termCounts = std::vector<uint64_t>(5, 0);
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> evs;                 // ring of per-iteration leg events
+    hipStream_t sT = nullptr, sN = nullptr;      // tree / network streams (native evaluator mode)
+    int* hActive = nullptr;
 };
 
 static bool start_game(hm_selfplay* s, Slot& sl, hm_board& out) {
@@ -164,25 +168,87 @@ static void finish_game(hm_selfplay* s, Slot& sl) {   // selfplay.cc:726-734
     sl.active = false;
 }
 
-static int run_search_lockstep(hm_selfplay* s) {
+static int eval_rows_sync(hm_selfplay* s, int which, int rows) {   // evaluator on the null stream (raw-policy plies, callback mode)
+    if (s->io.net_desc)
+        return hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], rows,
+                              s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr);
+    if (int rc = s->fn(s->user, which, rows)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
+    return 0;
+}
+
+static int run_search_lockstep(hm_selfplay* s, int minTarget) {
+    constexpr int RING = 256;
     int which = 0, active = 1, iters = 0;
-    if (!s->ev[0]) for (auto& e : s->ev) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
+    const bool native = s->io.net_desc != nullptr;
+    if (s->evs.empty()) {
+        s->evs.resize((size_t)RING * 6);
+        for (auto& e : s->evs) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
+    }
+    if (native && !s->sT) {
+        if (hipStreamCreateWithFlags(&s->sT, hipStreamNonBlocking) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
+        if (std::getenv("HM_SELFPLAY_SEQUENTIAL")) s->sN = s->sT;          // diagnostic: no collect/net overlap
+        else if (hipStreamCreateWithFlags(&s->sN, hipStreamNonBlocking) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
+        if (hipHostMalloc(reinterpret_cast<void**>(&s->hActive), sizeof(int), hipHostMallocDefault) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed");
+    }
+    if (native) (void)hipDeviceSynchronize();      // the prologue ran on the null stream
+    // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
+    // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
+    const int noPollBefore = minTarget / 8 - 1;
+    int harvested = 0;
+    auto harvest = [&](int upto) {                 // leg timings of iterations [harvested, upto)
+        for (int it = harvested; it < upto; ++it) {
+            hipEvent_t* e = &s->evs[(size_t)(it % RING) * 6];
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += ms;
+            if (hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) s->res.eval_ms += ms;
+            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += ms;
+        }
+        harvested = upto;
+    };
     while (active > 0) {
-        (void)hipEventRecord(s->ev[0], nullptr);
-        if (int rc = hm_sp_collect(s->sp, s->io.planes[which], s->io.planes[1 - which], nullptr)) return rc;
-        (void)hipEventRecord(s->ev[1], nullptr);
-        if (int rc = s->fn(s->user, which, s->G * 8)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
-        (void)hipEventRecord(s->ev[2], nullptr);
-        if (int rc = hm_sp_process(s->sp, s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr, nullptr)) return rc;
-        (void)hipEventRecord(s->ev[3], nullptr);
-        if (int rc = hm_sp_active(s->sp, &active)) return rc;     // syncs the stream
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) s->res.collect_ms += ms;
-        if (hipEventElapsedTime(&ms, s->ev[1], s->ev[2]) == hipSuccess) s->res.eval_ms += ms;
-        if (hipEventElapsedTime(&ms, s->ev[2], s->ev[3]) == hipSuccess) s->res.process_ms += ms;
+        hipEvent_t* e = &s->evs[(size_t)(iters % RING) * 6];
+        hipEvent_t* ePrev = &s->evs[(size_t)((iters + RING - 1) % RING) * 6];
+        const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
+        if (native) {
+            // tree stream: collect(next) -- net stream: forward(cur) -- tree stream: process(cur)
+            void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
+                              {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
+            void** h = hv[iters & 1];
+            (void)hipEventRecord(e[0], s->sT);
+            if (int rc = hm_sp_collect(s->sp, s->io.planes[1 - which], s->sT)) return rc;
+            (void)hipEventRecord(e[1], s->sT);
+            // planes[which] were completed by the previous iteration's collect, which precedes that
+            // iteration's process on the tree stream: its "process done" event orders the net stream
+            if (iters > 0) (void)hipStreamWaitEvent(s->sN, ePrev[5], 0);
+            (void)hipEventRecord(e[2], s->sN);
+            if (int rc = hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
+                                        h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+            (void)hipEventRecord(e[3], s->sN);
+            (void)hipStreamWaitEvent(s->sT, e[3], 0);
+            (void)hipEventRecord(e[4], s->sT);
+            if (int rc = hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT)) return rc;
+            (void)hipEventRecord(e[5], s->sT);
+            if (poll) {
+                if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;     // async copy + stream sync
+                active = *s->hActive;
+            }
+        } else {
+            (void)hipEventRecord(e[0], nullptr);
+            if (int rc = hm_sp_collect(s->sp, s->io.planes[1 - which], nullptr)) return rc;
+            (void)hipEventRecord(e[1], nullptr);
+            (void)hipEventRecord(e[2], nullptr);
+            if (int rc = s->fn(s->user, which, s->G * 8)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
+            (void)hipEventRecord(e[3], nullptr);
+            (void)hipEventRecord(e[4], nullptr);
+            if (int rc = hm_sp_process(s->sp, s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr, nullptr)) return rc;
+            (void)hipEventRecord(e[5], nullptr);
+            if (poll) if (int rc = hm_sp_active(s->sp, &active)) return rc;     // syncs the stream
+        }
         which = 1 - which;
         s->res.eval_batches += 1;
-        if (++iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
+        ++iters;
+        if (poll) harvest(iters);
+        if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
     }
     s->res.search_iterations += iters;
     return 0;
@@ -202,7 +268,9 @@ void hm_selfplay_config_default(hm_selfplay_config* c) {   // tools/selfplay.h:1
 }
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* scfg, const hm_eval_io* io, hm_eval_fn fn, void* user, hm_selfplay** out) {
-    if (!cfg || !io || !fn || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (!cfg || !io || (!fn && !io->net_desc) || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (io->net_desc && (!io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2))
+        return hm_fail(HM_ERR_INVALID, "native evaluator needs the second set of head buffers");
     const hm_selfplay_config& c = *cfg;
     if (c.games == 0 || c.nodes == 0 || c.max_macro_plies == 0) return hm_fail(HM_ERR_INVALID, "games, nodes, and max-macro-plies must be positive");
     if (c.raw_policy_mean_macro_plies < 0.0 || c.raw_policy_high_temperature_probability < 0.0 || c.raw_policy_high_temperature_probability > 1.0
@@ -230,6 +298,10 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->sp) hm_sp_destroy(s->sp);
     if (s->d_boards) (void)hipFree(s->d_boards);
     if (s->d_u8) (void)hipFree(s->d_u8);
+    if (s->sT) (void)hipStreamDestroy(s->sT);
+    if (s->sN && s->sN != s->sT) (void)hipStreamDestroy(s->sN);
+    if (s->hActive) (void)hipHostFree(s->hActive);
+    for (auto& e : s->evs) if (e) (void)hipEventDestroy(e);
     delete s;
     return 0;
 }
@@ -290,7 +362,7 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
         for (int g = 0; g < G; ++g) { Slot& sl = s->slots[g]; anyRaw |= sl.active && sl.rawActive && sl.macroPly < sl.initLength; }
         if (anyRaw) {
             if (int rc = hm_encode_planes(s->d_boards, G, HM_DT_F16, s->io.planes[0], nullptr)) return rc;
-            if (int rc = s->fn(s->user, 0, G)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
+            if (int rc = eval_rows_sync(s, 0, G)) return rc;
             s->res.eval_batches += 1;
             if (int rc = hm_sp_raw_policy(s->sp, s->io.pi_a, s->io.pi_b, rawMoves.data(), rawProbs.data(), rawCaps.data(), rawCounts.data(), rawOn.data())) return rc;
             std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0);
@@ -366,7 +438,9 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
             seeds[g] = mix_seed(s->runId, sl.gameIndex * c.max_macro_plies + sl.macroPly);
         }
         if (int rc = hm_sp_begin_search(s->sp, target.data(), seeds.data(), c.dirichlet_alpha, c.dirichlet_epsilon, mask.data())) return rc;
-        if (int rc = run_search_lockstep(s)) return rc;
+        int minTarget = 1 << 30;
+        for (int g = 0; g < G; ++g) if (mask[g] && target[g] < minTarget) minTarget = target[g];
+        if (int rc = run_search_lockstep(s, minTarget)) return rc;
         if (int rc = hm_sp_root_stats(s->sp, counts.data(), mA.data(), mB.data(), visits.data(), nullptr, nullptr, rootQ.data(), info.data(), E)) return rc;
         std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0);
         std::vector<uint8_t> applyMask(G, 0);

@@ -32,7 +32,7 @@ _SIGS = {
     "hm_sp_destroy": (_i, [_vp]),
     "hm_sp_set_games": (_i, [_vp, _vp, _vp]),
     "hm_sp_begin_search": (_i, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
-    "hm_sp_collect": (_i, [_vp, _vp, _vp, _vp]),
+    "hm_sp_collect": (_i, [_vp, _vp, _vp]),
     "hm_sp_process": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp]),
     "hm_sp_max_edges": (_i, [_vp]),
     "hm_sp_active": (_i, [_vp, C.POINTER(_i)]),
@@ -116,7 +116,7 @@ class SearchEngine:
 
     def collect(self):
         st = torch.cuda.current_stream().cuda_stream
-        check(lib.hm_sp_collect(self.h, self.planes[self.cur].data_ptr(), self.planes[1 - self.cur].data_ptr(), st))
+        check(lib.hm_sp_collect(self.h, self.planes[1 - self.cur].data_ptr(), st))
         return self.planes[self.cur]
 
     def process(self, value, pi_a, pi_b, wdl, moves_left, want_active=True) -> int:

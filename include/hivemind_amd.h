@@ -156,9 +156,10 @@ int hm_perft(const hm_board* root, int depth, int shard, int nshards, uint64_t* 
 /* [G*8, 3] ordered loss,draw,win, moves_left [G*8]                     */
 /* (searchthread.cc:474-484, 576-578, 609-617).  Row g*8+k belongs to   */
 /* game g; unused rows are ignored.  One lockstep iteration =           */
-/* hm_sp_collect -> net(planes_cur) -> hm_sp_process, then the caller   */
-/* swaps planes_cur / planes_next (the reference's double-buffered      */
-/* lookahead, searchthread.cc:661-708).                                 */
+/* hm_sp_collect(planes_next) || net(planes_cur) -> hm_sp_process, then */
+/* the caller swaps planes_cur / planes_next (the reference's           */
+/* double-buffered lookahead, searchthread.cc:661-708): collect only    */
+/* writes planes_next, so it may overlap the network on another stream. */
 /* ================================================================== */
 typedef struct hm_sp hm_sp;
 
@@ -186,7 +187,7 @@ int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask);
  * TT setup (agent.cc:421-558).  Dirichlet noise (alpha, eps, per-game rootNoiseSeed) as
  * node.h:286-315; alpha == 0 disables it. */
 int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask);
-int hm_sp_collect(hm_sp* sp, void* d_planes_cur, void* d_planes_next, void* stream);
+int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream);
 /* active_games (host, optional): number of games still searching after this step (forces a sync). */
 int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl,
                   const void* d_moves_left, int* active_games, void* stream);
@@ -253,6 +254,11 @@ void hm_selfplay_config_default(hm_selfplay_config* cfg);
 typedef struct hm_eval_io {
     void* planes[2];
     void* value; void* pi_a; void* pi_b; void* wdl; void* moves_left;
+    /* Optional native evaluator: when net_desc != NULL the driver calls hm_net_forward itself
+     * (no callback) on a second stream, overlapping it with hm_sp_collect; *_2 is the second set
+     * of head buffers the overlap needs. */
+    const int32_t* net_desc; uint64_t net_desc_ints; const void* net_wh; const void* net_wf;
+    void* value_2; void* pi_a_2; void* pi_b_2; void* wdl_2; void* moves_left_2;
 } hm_eval_io;
 /* Runs the network on the first `rows` rows of planes[which] and fills the head buffers
  * (Engine::enqueueInferenceHalf + synchronizeInferenceHalf).  Return 0 on success. */

@@ -42,4 +42,7 @@ for s in samples:
 print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searched_positions, nodes=res.total_nodes,
                       eval_rows=res.eval_rows, eval_batches=res.eval_batches, iters=res.search_iterations, raw=res.raw_plies,
                       seconds=res.seconds, wall=dt, positions_per_s=res.samples / res.seconds, nodes_per_s=res.total_nodes / res.seconds,
-                      term=list(res.terminations), bytes=res.record_bytes, chunk_samples=len(samples))))
+                      term=list(res.terminations), bytes=res.record_bytes, chunk_samples=len(samples),
+                      leg_ms=dict(collect=res.collect_ms / max(res.search_iterations, 1), net=res.eval_ms / max(res.search_iterations, 1),
+                                  process=res.process_ms / max(res.search_iterations, 1)),
+                      iter_ms=res.seconds * 1e3 / max(res.eval_batches, 1))))
