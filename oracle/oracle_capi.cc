@@ -196,6 +196,27 @@ void ora_hash_evaluator(const uint16_t* planes, int n, uint16_t* value, uint16_t
     std::memcpy(piB, o.piB.data(), 2 * o.piB.size()); std::memcpy(wdl, o.wdl.data(), 2 * o.wdl.size());
     std::memcpy(ml, o.movesLeft.data(), 2 * (size_t)n);
 }
+// JointCandidateGenerator driven to exhaustion: returns the number of candidates, writes (moveA, moveB, jointPrior)
+int ora_gen_enumerate(const uint32_t* a, int nA, const uint32_t* b, int nB, const float* pa, const float* pb, int adv, int aOn, int bOn,
+                      const uint8_t* ca, const uint8_t* cb, int tie_mode, uint32_t* outA, uint32_t* outB, float* outP, int cap) {
+    CandidateGenerator g;
+    g.initialize(std::vector<Move>(a, a + nA), std::vector<Move>(b, b + nB), std::vector<float>(pa, pa + nA), std::vector<float>(pb, pb + nB),
+                 adv != 0, aOn != 0, bOn != 0, ca ? std::vector<uint8_t>(ca, ca + nA) : std::vector<uint8_t>(),
+                 cb ? std::vector<uint8_t>(cb, cb + nB) : std::vector<uint8_t>(), tie_mode);
+    int n = 0;
+    while (g.hasNext()) {
+        Candidate c = g.getNext();
+        if (n < cap) { outA[n] = c.moveA; outB[n] = c.moveB; outP[n] = c.jointPrior; }
+        ++n;
+    }
+    return n;
+}
+float ora_joint_prior(uint32_t mA, float pA, uint32_t mB, float pB, int aOn, int bOn, int adv, int aCan, int bCan, int capA, int capB) {
+    JointActionRules r{aOn != 0, bOn != 0, adv != 0, aCan != 0, bCan != 0};
+    return Candidate(mA, pA, 0, mB, pB, 0, r, capA != 0, capB != 0).jointPrior;
+}
+int ora_is_double_sit_legal(int adv, int aOn, int bOn) { return is_double_sit_legal(adv != 0, aOn != 0, bOn != 0); }
+int ora_is_single_pass_legal(int adv, int aOn, int bOn, int cap) { return is_single_pass_legal(adv != 0, aOn != 0, bOn != 0, cap != 0); }
 int ora_pw_allowed_children(int visits, int isRoot) { return get_allowed_children(visits, isRoot ? 4.0f : 2.0f, 0.4f); }
 float ora_get_cpuct(float v) { return get_cpuct(v, 2.5f, 19652.0f); }
 float ora_portable_expf(float x) { return portable_expf(x); }
