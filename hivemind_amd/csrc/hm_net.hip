@@ -77,9 +77,33 @@ __device__ __forceinline__ const h16* frag_src(const h16* act, int lda, int zero
     return act + (size_t)row * lda + col;
 }
 
-// k-steps are processed in groups of KG: all weight-fragment loads of a group (KG x tiles, 1 KiB each
-// per wave) are issued before the first MFMA of the group, so their L2 latency overlaps instead of
-// serialising one load per MFMA.
+// k-steps are processed in groups of KG with a two-deep software pipeline: the weight-fragment
+// loads (KG x tiles, 1 KiB per wave-load, L2-resident) and LDS activation-fragment reads of group
+// g+1 are issued before the MFMAs of group g, so the L2 latency of one group hides behind the
+// matrix work of the previous one instead of serialising load -> MFMA -> load.
+template <int MAXT, int KG>
+struct FragGroup { half8 a[KG]; half8 b[KG][MAXT]; };
+
+template <int MAXT, int KG>
+__device__ __forceinline__ void load_group_rows(FragGroup<MAXT, KG>& g, const h16* act, int lda, int zeroRow, bool conv3, int cin,
+                                                const h16* w, int ntiles, int ks, int t0, int kh, int sq, int lane) {
+#pragma unroll
+    for (int u = 0; u < KG; ++u) {
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) g.b[u][i] = wfrag(w, ntiles, ks + u, t0 + 2 * i, lane);
+    }
+#pragma unroll
+    for (int u = 0; u < KG; ++u) g.a[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
+}
+template <int MAXT, int KG>
+__device__ __forceinline__ void mfma_group_rows(floatx16 (&acc)[MAXT], const FragGroup<MAXT, KG>& g) {
+#pragma unroll
+    for (int u = 0; u < KG; ++u) {
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) acc[i] = mfma(g.a[u], g.b[u][i], acc[i]);
+    }
+}
+
 template <int MAXT>
 __device__ __forceinline__ void gemm_rows(floatx16 (&acc)[MAXT], const h16* act, int lda, int zeroRow, bool conv3, int cin,
                                           int ksteps, const h16* w, int ncol, int wave, int lane) {
@@ -88,23 +112,18 @@ __device__ __forceinline__ void gemm_rows(floatx16 (&acc)[MAXT], const h16* act,
     const int sq = (wave & 1) * 32 + (lane & 31);
     const int kh = 8 * (lane >> 5);
     const int t0 = wave >> 1;
-    int ks = 0;
-    for (; ks + KG <= ksteps; ks += KG) {
-        half8 a[KG], b[KG][MAXT];
-#pragma unroll
-        for (int u = 0; u < KG; ++u) {
-#pragma unroll
-            for (int i = 0; i < MAXT; ++i) b[u][i] = wfrag(w, ntiles, ks + u, t0 + 2 * i, lane);
-        }
-#pragma unroll
-        for (int u = 0; u < KG; ++u) a[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
-#pragma unroll
-        for (int u = 0; u < KG; ++u) {
-#pragma unroll
-            for (int i = 0; i < MAXT; ++i) acc[i] = mfma(a[u], b[u][i], acc[i]);
-        }
+    const int ngroups = ksteps / KG;
+    FragGroup<MAXT, KG> g0, g1;
+    if (ngroups > 0) load_group_rows<MAXT, KG>(g0, act, lda, zeroRow, conv3, cin, w, ntiles, 0, t0, kh, sq, lane);
+    int gi = 0;
+    for (; gi + 2 <= ngroups; gi += 2) {
+        load_group_rows<MAXT, KG>(g1, act, lda, zeroRow, conv3, cin, w, ntiles, (gi + 1) * KG, t0, kh, sq, lane);
+        mfma_group_rows<MAXT, KG>(acc, g0);
+        if (gi + 2 < ngroups) load_group_rows<MAXT, KG>(g0, act, lda, zeroRow, conv3, cin, w, ntiles, (gi + 2) * KG, t0, kh, sq, lane);
+        mfma_group_rows<MAXT, KG>(acc, g1);
     }
-    for (; ks < ksteps; ++ks) {
+    if (gi < ngroups) mfma_group_rows<MAXT, KG>(acc, g0);
+    for (int ks = ngroups * KG; ks < ksteps; ++ks) {
         const half8 a = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks, kh, sq));
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) acc[i] = mfma(a, wfrag(w, ntiles, ks, t0 + 2 * i, lane), acc[i]);
@@ -112,24 +131,40 @@ __device__ __forceinline__ void gemm_rows(floatx16 (&acc)[MAXT], const h16* act,
 }
 
 // Transposed GEMM: D[ch][sq] = sum_k W[k][ch] * act[sq][k]; one 32x32 tile per call
-// (channel tile `wtile` of the packed matrix, square tile = wave & 1).
+// (channel tile `wtile` of the packed matrix, square tile = wave & 1).  Same two-deep pipeline.
+template <int KG>
+struct FragGroupT { half8 a[KG]; half8 b[KG]; };
+template <int KG>
+__device__ __forceinline__ void load_group_cols(FragGroupT<KG>& g, const h16* act, int lda, int zeroRow, bool conv3, int cin,
+                                                const h16* w, int ntilesTotal, int wtile, int ks, int kh, int sq, int lane) {
+#pragma unroll
+    for (int u = 0; u < KG; ++u) g.a[u] = wfrag(w, ntilesTotal, ks + u, wtile, lane);
+#pragma unroll
+    for (int u = 0; u < KG; ++u) g.b[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
+}
 __device__ __forceinline__ floatx16 gemm_cols(const h16* act, int lda, int zeroRow, bool conv3, int cin, int ksteps,
                                               const h16* w, int ntilesTotal, int wtile, int wave, int lane) {
-    constexpr int KG = 8;
+    constexpr int KG = 4;
     floatx16 acc = zero16();
     const int sq = (wave & 1) * 32 + (lane & 31);
     const int kh = 8 * (lane >> 5);
-    int ks = 0;
-    for (; ks + KG <= ksteps; ks += KG) {
-        half8 a[KG], b[KG];
+    const int ngroups = ksteps / KG;
+    FragGroupT<KG> g0, g1;
+    if (ngroups > 0) load_group_cols<KG>(g0, act, lda, zeroRow, conv3, cin, w, ntilesTotal, wtile, 0, kh, sq, lane);
+    int gi = 0;
+    for (; gi + 2 <= ngroups; gi += 2) {
+        load_group_cols<KG>(g1, act, lda, zeroRow, conv3, cin, w, ntilesTotal, wtile, (gi + 1) * KG, kh, sq, lane);
 #pragma unroll
-        for (int u = 0; u < KG; ++u) a[u] = wfrag(w, ntilesTotal, ks + u, wtile, lane);
+        for (int u = 0; u < KG; ++u) acc = mfma(g0.a[u], g0.b[u], acc);       // A = W^T fragment, B = act^T fragment
+        if (gi + 2 < ngroups) load_group_cols<KG>(g0, act, lda, zeroRow, conv3, cin, w, ntilesTotal, wtile, (gi + 2) * KG, kh, sq, lane);
 #pragma unroll
-        for (int u = 0; u < KG; ++u) b[u] = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks + u, kh, sq));
-#pragma unroll
-        for (int u = 0; u < KG; ++u) acc = mfma(a[u], b[u], acc);       // A = W^T fragment, B = act^T fragment
+        for (int u = 0; u < KG; ++u) acc = mfma(g1.a[u], g1.b[u], acc);
     }
-    for (; ks < ksteps; ++ks) {
+    if (gi < ngroups) {
+#pragma unroll
+        for (int u = 0; u < KG; ++u) acc = mfma(g0.a[u], g0.b[u], acc);
+    }
+    for (int ks = ngroups * KG; ks < ksteps; ++ks) {
         const half8 b = *reinterpret_cast<const half8*>(frag_src(act, lda, zeroRow, conv3, cin, ks, kh, sq));
         acc = mfma(wfrag(w, ntilesTotal, ks, wtile, lane), b, acc);
     }

@@ -1046,7 +1046,8 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
 // searchthread.cc:680-688).  A game with no batch in flight collects its first batch into NEXT and
 // marks it `fresh`; its lookahead follows one iteration later (same order of tree operations as
 // run_iteration: collect b0, collect b1, process b0).
-__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext) {
+__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* activeCount) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     stage_table(&s_rt, pl.rules);
@@ -1686,7 +1687,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
 int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
-                       static_cast<uint16_t*>(d_planes_next));
+                       static_cast<uint16_t*>(d_planes_next), sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1695,7 +1696,6 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
                   int* active_games, void* stream) {
     if (!sp || !d_value || !d_pi_a || !d_pi_b || !d_wdl || !d_moves_left) return hm_fail(HM_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCHK(hipMemsetAsync(sp->d_active, 0, sizeof(int), st));
     NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
              static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
     hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64 * BATCH), 0, st, sp->pl, sp->prm, o, sp->d_active);

@@ -195,13 +195,15 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
     const int noPollBefore = minTarget / 8 - 1;
     int harvested = 0;
-    auto harvest = [&](int upto) {                 // leg timings of iterations [harvested, upto)
+    auto harvest = [&](int upto) {                 // leg timings of the sampled iterations in [harvested, upto)
         for (int it = harvested; it < upto; ++it) {
+            if (native && (it & 7) != 0) continue;
             hipEvent_t* e = &s->evs[(size_t)(it % RING) * 6];
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += ms;
-            if (hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) s->res.eval_ms += ms;
-            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += ms;
+            const double w = native ? 8.0 : 1.0;   // each sample stands for 8 iterations
+            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += w * ms;
+            if (hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) s->res.eval_ms += w * ms;
+            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += w * ms;
         }
         harvested = upto;
     };
@@ -209,23 +211,26 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         hipEvent_t* e = &s->evs[(size_t)(iters % RING) * 6];
         hipEvent_t* ePrev = &s->evs[(size_t)((iters + RING - 1) % RING) * 6];
         const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
+        const bool timed = (iters & 7) == 0;       // leg timing is sampled: event records are not free
         if (native) {
             // tree stream: collect(next) -- net stream: forward(cur) -- tree stream: process(cur)
             void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
                               {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
             void** h = hv[iters & 1];
-            (void)hipEventRecord(e[0], s->sT);
+            if (timed) (void)hipEventRecord(e[0], s->sT);
             if (int rc = hm_sp_collect(s->sp, s->io.planes[1 - which], s->sT)) return rc;
-            (void)hipEventRecord(e[1], s->sT);
-            // planes[which] were completed by the previous iteration's collect, which precedes that
-            // iteration's process on the tree stream: its "process done" event orders the net stream
+            if (timed) (void)hipEventRecord(e[1], s->sT);
+            // planes[which] were completed by the previous iteration's collect.  The forward could start
+            // right after it, but measured on MI355X it then shares CUs with k_process (8-wave blocks,
+            // 79 KB LDS), which stretches from 0.12 to 0.33 ms and lengthens the critical path; so the
+            // forward is ordered behind process(i-1) and overlaps only collect(i).
             if (iters > 0) (void)hipStreamWaitEvent(s->sN, ePrev[5], 0);
-            (void)hipEventRecord(e[2], s->sN);
+            if (timed) (void)hipEventRecord(e[2], s->sN);
             if (int rc = hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
                                         h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
             (void)hipEventRecord(e[3], s->sN);
             (void)hipStreamWaitEvent(s->sT, e[3], 0);
-            (void)hipEventRecord(e[4], s->sT);
+            if (timed) (void)hipEventRecord(e[4], s->sT);
             if (int rc = hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT)) return rc;
             (void)hipEventRecord(e[5], s->sT);
             if (poll) {
