@@ -70,6 +70,7 @@ def cpu_selfplay_baseline(model, nodes, seconds=20.0):
     torch on the host cores: searched positions per second on a bounded sample of start-of-game roots."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))          # batch-8 evaluations do not scale past a few cores
     cpu_model = model.float().eval()
 
     def ev(planes_u16):
@@ -218,6 +219,16 @@ def main():
                             "games_per_gpu": args.games, "nodes": args.nodes, "sharding": f"games x{world}, record gather only"},
                     roofline=roof)
         if not args.no_extra and world == 1:
+            # the same engine with more games in flight (the 64-game configuration is latency-bound)
+            cfg = hm.default_selfplay_config(games=256, nodes=args.nodes, seed=77, concurrent_games=256)
+            sp = hm.SelfPlay(cfg, net, device=dev)
+            r = sp.run()
+            sp.close()
+            it256 = max(r.search_iterations, 1)
+            extra["selfplay_256_concurrent_games"] = {"positions_per_s": r.samples / r.seconds, "nodes_per_s": r.total_nodes / r.seconds,
+                                                      "leg_ms_per_iteration": {"collect": r.collect_ms / it256, "net": r.eval_ms / it256,
+                                                                               "process": r.process_ms / it256},
+                                                      "net_TFLOPs": 2048 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
             pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
             extra["plane_encode_64k"] = pl
             if rank == 0 and not args.no_cpu_baseline:
