@@ -36,9 +36,9 @@ def _roots(n, seed):
     return boards
 
 
-@pytest.mark.parametrize("nodes,noise", [(400, False), (400, True), (100, False)])
+@pytest.mark.parametrize("nodes,noise", [(400, False), (400, True), (100, False), (1600, True)])
 def test_search_matches_oracle(hm, nodes, noise):
-    G = 24
+    G = 24 if nodes <= 400 else 8           # BASELINE configs[4]: nodes=1600, transposition-sharing MCGS + Dirichlet noise
     roots = _roots(G, 77 + nodes)
     roots[0] = O.Board().compact(0, False)[0]
     eng = hm.SearchEngine(G, 1700)
