@@ -17,6 +17,7 @@
 // MFMA issue + LDS fragment reads (M = 64 rows per workgroup), not by HBM.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -428,7 +429,8 @@ int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, cons
         if (hipMemcpy(d_ring + slot, &nd, sizeof nd, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "descriptor upload failed");
     }
     const NetDesc* d_nd = d_ring + slot;
-    const int grid = n < 1024 ? n : 1024;
+    static const int maxBlocks = std::getenv("HM_NET_MAX_BLOCKS") ? std::atoi(std::getenv("HM_NET_MAX_BLOCKS")) : 1024;
+    const int grid = n < maxBlocks ? n : maxBlocks;
     auto args = [&](auto kern) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -1040,20 +1040,13 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
 // =======================================================================================
 // kernels (one wave / block of 64 threads per game)
 // =======================================================================================
-// One lockstep iteration, collect side.  The kernel only ever writes the NEXT plane tensor, so it
-// is independent of the network launch that reads CUR and the two overlap on separate streams
+// One lockstep iteration, collect side.  Only the NEXT plane tensor is written, so this is
+// independent of the network launch that reads CUR and the two overlap on separate streams
 // (the reference overlaps collect_batch with the in-flight TensorRT batch the same way,
 // searchthread.cc:680-688).  A game with no batch in flight collects its first batch into NEXT and
 // marks it `fresh`; its lookahead follows one iteration later (same order of tree operations as
-// run_iteration: collect b0, collect b1, process b0).
-__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* activeCount) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
-    __shared__ RulesTab s_rt;
-    __shared__ WaveLds L;
-    stage_table(&s_rt, pl.rules);
-    __syncthreads();
-    const int g = blockIdx.x;
-    G s = make_view(pl, prm, g);
+// run_iteration: collect b0, collect b1, process b0).  Runs on one wave.
+__device__ inline void collect_step(G& s, const RulesTab& rt, WaveLds& L, uint16_t* planesNext, int g) {
     if (s.g->status != ST_SEARCHING) return;
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
@@ -1061,24 +1054,21 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
     // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
     while (s.g->pending < 0) {
         if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
-        collect_batch(s, s_rt, L, 0, rootTeam, rootAdv, nxt);
+        collect_batch(s, rt, L, 0, rootTeam, rootAdv, nxt);
         if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return; }   // no progress possible
-        if (s.g->validCount[0] == 0) { process_batch(s, s_rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
+        if (s.g->validCount[0] == 0) { process_batch(s, rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
         s.g->pending = 0;
         s.g->fresh = 1;
         return;
     }
     if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
-    collect_batch(s, s_rt, L, 1 - s.g->pending, rootTeam, rootAdv, nxt);
+    collect_batch(s, rt, L, 1 - s.g->pending, rootTeam, rootAdv, nxt);
 }
 
-__global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
-    __shared__ RulesTab s_rt;
-    __shared__ ExpLds s_exp[BATCH];
-    stage_table(&s_rt, pl.rules);
-    __syncthreads();
-    const int g = blockIdx.x, wave = threadIdx.x >> 6;
-    G s = make_view(pl, prm, g);
+// One lockstep iteration, process side, for a block of BATCH waves.  Returns on every wave; only
+// wave 0 executes the ordered tail.  `activeCount` receives +1 for a game that is still searching.
+__device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const NetOut& out, int g, int* activeCount) {
+    const int wave = threadIdx.x >> 6;
     const int st = s.g->status;
     if (st != ST_SEARCHING && st != ST_FINISHING) return;      // uniform across the block
     const int rootTeam = s.g->team;
@@ -1087,34 +1077,77 @@ __global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, Ne
     if (st == ST_SEARCHING && s.g->fresh) {                    // first batch of this game is still waiting for its evaluation
         __syncthreads();
         if (threadIdx.x == 0) { s.g->fresh = 0; atomicAdd(activeCount, 1); }
+        __syncthreads();
         return;
     }
     const int pending = s.g->pending;
     const bool solvedOrOverflow = s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow;
     const bool doProcess = pending >= 0 && !(st == ST_FINISHING && solvedOrOverflow);
     // phase A: one leaf expansion per wave
-    if (doProcess && wave < s.g->ctxCount[pending]) expand_context(s, s_rt, s_exp[wave], pending, wave, rootTeam, rootAdv, &out, rowBase);
+    if (doProcess && wave < s.g->ctxCount[pending]) expand_context(s, rt, exp[wave], pending, wave, rootTeam, rootAdv, &out, rowBase);
     __threadfence_block();
     __syncthreads();
-    if (wave != 0) return;
-    // phase B (wave 0): ordered backups and the run_iteration / finish_pending tail
-    if (st == ST_FINISHING) {
-        // finish_pending_iteration / discard_pending_iteration (agent.cc:343-352)
-        if (pending >= 0) {
+    if (wave == 0) {
+        // phase B (wave 0): ordered backups and the run_iteration / finish_pending tail
+        if (st == ST_FINISHING) {
+            // finish_pending_iteration / discard_pending_iteration (agent.cc:343-352)
+            if (pending >= 0) {
+                s.g->pending = -1;
+                if (solvedOrOverflow) abort_batch(s, pending);
+                else backup_batch(s, pending, &out, rowBase);
+            }
+            s.g->status = s.g->overflow ? ST_ERROR : ST_DONE;
+        } else if (pending < 0) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
+        } else {
+            const int look = 1 - pending;
             s.g->pending = -1;
-            if (solvedOrOverflow) abort_batch(s, pending);
-            else backup_batch(s, pending, &out, rowBase);
+            backup_batch(s, pending, &out, rowBase);
+            if (s.g->validCount[look] == 0) process_batch(s, rt, exp[0], look, rootTeam, rootAdv, nullptr, 0);
+            else s.g->pending = look;
+            if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
         }
-        s.g->status = s.g->overflow ? ST_ERROR : ST_DONE;
-        return;
     }
-    if (pending < 0) { if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1); return; }
-    const int look = 1 - pending;
-    s.g->pending = -1;
-    backup_batch(s, pending, &out, rowBase);
-    if (s.g->validCount[look] == 0) process_batch(s, s_rt, s_exp[0], look, rootTeam, rootAdv, nullptr, 0);
-    else s.g->pending = look;
-    if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* activeCount) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    G s = make_view(pl, prm, blockIdx.x);
+    collect_step(s, s_rt, L, planesNext, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
+    __shared__ RulesTab s_rt;
+    __shared__ ExpLds s_exp[BATCH];
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    G s = make_view(pl, prm, blockIdx.x);
+    process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
+}
+
+// Fused tree step of the pipelined driver: process(batch i-1) then collect(batch i+1) in ONE launch
+// (the forward of batch i runs beside it on the network stream).  activeCount[parity] is counted here,
+// activeCount[parity ^ 1] is cleared for the next launch.
+union StepLds {
+    ExpLds exp[BATCH];
+    WaveLds wave;
+};
+__global__ __launch_bounds__(64 * BATCH) void k_step(Pools pl, Params prm, NetOut out, uint16_t* planesNext, int* activeCount, int parity) {
+    __shared__ RulesTab s_rt;
+    __shared__ StepLds L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) activeCount[parity ^ 1] = 0;
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    G s = make_view(pl, prm, blockIdx.x);
+    process_step(s, s_rt, L.exp, out, blockIdx.x, activeCount + parity);
+    if ((threadIdx.x >> 6) != 0) return;
+    collect_step(s, s_rt, L.wave, planesNext, blockIdx.x);
 }
 
 // Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
@@ -1488,6 +1521,9 @@ __global__ __launch_bounds__(64) void k_rules_probe(const RulesTab* rules, const
 
 struct hm_sp;
 extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
+extern "C" int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
+                          void* d_planes_next, int parity, hipStream_t stream);
+extern "C" int hm_sp_active2_on(hm_sp* sp, int parity, int* pinned_out, hipStream_t stream);
 
 // =========================================================================================
 // host side
@@ -1504,6 +1540,7 @@ struct hm_sp {
     RootOut ro;
     u64* d_rootHash;
     int* d_active;
+    int* d_active2;
     int* d_target;
     u64* d_seed;
     uint8_t* d_mask;
@@ -1622,7 +1659,7 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * 12);
-    rc |= dalloc(sp, &sp->d_rootHash, G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_target, G_);
+    rc |= dalloc(sp, &sp->d_rootHash, G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_active2, 2); rc |= dalloc(sp, &sp->d_target, G_);
     rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
     rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
@@ -1724,6 +1761,21 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+// fused process(previous heads) + collect(next planes); counts active games into d_active2[parity]
+int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
+               void* d_planes_next, int parity, hipStream_t stream) {
+    NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
+             static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
+    hipLaunchKernelGGL(k_step, dim3(sp->nGames), dim3(64 * BATCH), 0, stream, sp->pl, sp->prm, o, static_cast<uint16_t*>(d_planes_next),
+                       sp->d_active2, parity & 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int hm_sp_active2_on(hm_sp* sp, int parity, int* pinned_out, hipStream_t stream) {
+    HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active2 + (parity & 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
 int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream) {
     HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
