@@ -51,6 +51,7 @@ _SIGS = {
     "hm_make_moves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "hm_perft": (_i, [_vp, _i, _i, _i, _u64p, C.POINTER(C.c_double)]),
     "hm_net_forward": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_profile": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)      # AttributeError here = header/library mismatch

@@ -207,9 +207,13 @@ __device__ __forceinline__ void depthwise_rows(const h16* y1 /*[66] row of this 
 
 template <int CT, bool K5>      // CT = C / 64 accumulator tiles per wave; K5 = some block uses a 5x5 depthwise
 __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
-                                                           const h16* __restrict__ planes, int n,
+                                                           const h16* __restrict__ planes, int n, int stageBytes,
                                                            h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
-                                                           h16* __restrict__ wdl, h16* __restrict__ ml) {
+                                                           h16* __restrict__ wdl, h16* __restrict__ ml,
+                                                           unsigned long long* __restrict__ dbg) {
+    // diagnostic stamps (dbg != nullptr only from hm_net_profile): cycle counter at phase boundaries of block 0
+    int dbgN = 0;
+#define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const NetDesc& nd = *ndp;                 // descriptor stays in (scalar-loadable) global memory
     const int C = nd.C;
@@ -220,9 +224,13 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
     h16* Y2 = Y1 + 64 * 66;                                       // [64][72]    depthwise output [sq][ch]
     float* Mv = reinterpret_cast<float*>(Y2 + 64 * 72);           // [C] channel means / scratch
     float* Gv = Mv + C;                                           // [C] gates / scratch
+    // optional per-block parameter stage (biases + depthwise weights): one coalesced copy per block
+    // instead of latency-exposed global loads in every chunk phase
+    unsigned char* Pst = reinterpret_cast<unsigned char*>(Gv + C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
+        HM_STAMP();   // 0: start
         // ---- input planes: NCHW [74][64] fp16 -> Ss as [sq][cin_pad] (+ zero row 64)
         const int ldi = nd.cin_pad + 8;
         for (int i = tid; i < 65 * ldi; i += 256) Ss[i] = (h16)0.0f;
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
         const h16* pin = planes + (size_t)sIdx * HM_PLANE_VALUES;
         for (int i = tid; i < HM_PLANE_VALUES; i += 256) Ss[(i & 63) * ldi + (i >> 6)] = pin[i];
         __syncthreads();
+        HM_STAMP();   // 1: input staged
         // ---- stem: 3x3 conv cin -> C, + bias, ReLU
         {
             floatx16 acc[CT];
@@ -250,8 +259,10 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
             }
         }
         __syncthreads();
+        HM_STAMP();   // 2: stem done
         // ---- mobile bottleneck blocks
         for (int bi = 0; bi < nd.nblocks; ++bi) {
+            HM_STAMP();   // block start
             const BlockDesc bd = nd.blk[bi];
             if (bd.eca) {   // x = x * hardsigmoid(W_eca . mean_sq(x) + b)   (builder_util.py:49-80, centre tap)
                 for (int c = tid; c < C; c += 256) {
@@ -263,7 +274,13 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
                 const h16* we = wh + bd.ecaw;                     // [ci][co]
                 for (int co = tid; co < C; co += 256) {
                     float s = wf[bd.ecab + co];
-                    for (int ci = 0; ci < C; ++ci) s += (float)we[(size_t)ci * C + co] * Mv[ci];
+                    for (int ci0 = 0; ci0 < C; ci0 += 16) {            // 16 independent (coalesced) loads in flight
+                        h16 wv[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) wv[u] = we[(size_t)(ci0 + u) * C + co];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) s += (float)wv[u] * Mv[ci0 + u];
+                    }
                     Gv[co] = fminf(fmaxf(s * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
                 }
                 __syncthreads();
@@ -273,10 +290,26 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
                 }
                 __syncthreads();
             }
+            const int cop = bd.cop, kk = bd.k;
+            const float* pb1 = wf + bd.b1;
+            const float* pb2 = wf + bd.b2;
+            const float* pb3 = wf + bd.b3;
+            const h16* pdw = wh + bd.dw;
+            if (stageBytes > 0) {
+                float* sb1 = reinterpret_cast<float*>(Pst);
+                float* sb2 = sb1 + cop;
+                float* sb3 = sb2 + cop;
+                h16* sdw = reinterpret_cast<h16*>(sb3 + C);
+                for (int i = tid; i < cop; i += 256) { sb1[i] = pb1[i]; sb2[i] = pb2[i]; }
+                for (int i = tid; i < C; i += 256) sb3[i] = pb3[i];
+                for (int i = tid; i < cop * kk * kk; i += 256) sdw[i] = pdw[i];
+                pb1 = sb1; pb2 = sb2; pb3 = sb3; pdw = sdw;
+                __syncthreads();
+            }
+            HM_STAMP();   // eca + param stage done
             floatx16 acc[CT];
 #pragma unroll
             for (int i = 0; i < CT; ++i) acc[i] = zero16();
-            const int cop = bd.cop, kk = bd.k;
             const int copTiles = cop >> 5;
             for (int c0 = 0; c0 < cop; c0 += 64) {
                 const int cw = cop - c0 < 64 ? cop - c0 : 64;       // 64 or 32 channels in this chunk
@@ -288,31 +321,34 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
                         const int ch = (wave >> 1) * 32 + drow(rg, lane);
-                        Y1[ch * 66 + sq] = (h16)fmaxf(e[rg] + wf[bd.b1 + c0 + ch], 0.0f);
+                        Y1[ch * 66 + sq] = (h16)fmaxf(e[rg] + pb1[c0 + ch], 0.0f);
                     }
                 }
                 __syncthreads();
+                HM_STAMP();   // expand done
                 // depthwise kxk (+bias, ReLU): thread = (channel, 2 board rows); output transposed to [sq][ch]
                 {
                     const int ch = tid & 63, g = tid >> 6;
                     if (ch < cw) {
-                        const h16* wd = wh + bd.dw + (size_t)(c0 + ch) * kk * kk;
-                        const float bias = wf[bd.b2 + c0 + ch];
+                        const h16* wd = pdw + (size_t)(c0 + ch) * kk * kk;
+                        const float bias = pb2[c0 + ch];
                         if (!K5 || kk == 3) depthwise_rows<3>(Y1 + ch * 66, Y2, ch, g, wd, bias);
                         else depthwise_rows<5>(Y1 + ch * 66, Y2, ch, g, wd, bias);
                     }
                 }
                 __syncthreads();
+                HM_STAMP();   // depthwise done
                 // 1x1 project: acc[sq][co] += Y2[sq][chunk] . W2[chunk][co]
                 if (cw == 64) gemm_rows<CT>(acc, Y2, 72, 0, false, 64, 4, wh + bd.w2 + (size_t)(c0 >> 4) * (C >> 5) * 512, C, wave, lane);
                 else          gemm_rows<CT>(acc, Y2, 72, 0, false, 64, 2, wh + bd.w2 + (size_t)(c0 >> 4) * (C >> 5) * 512, C, wave, lane);
                 __syncthreads();
+                HM_STAMP();   // project done
             }
             // residual: x = x + (acc + b3); every wave owns disjoint (sq, co) elements
 #pragma unroll
             for (int i = 0; i < CT; ++i) {
                 const int co = ((wave >> 1) + 2 * i) * 32 + (lane & 31);
-                const float bias = wf[bd.b3 + co];
+                const float bias = pb3[co];
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const int sq = (wave & 1) * 32 + drow(rg, lane);
@@ -321,6 +357,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
             }
             __syncthreads();
         }
+        HM_STAMP();   // blocks done
         // ---- value head: 1x1 conv C -> cv (+bias, ReLU), NCHW flatten, linear -> (wdl x3, plys)
         {
             const int cv = nd.cv;                                  // <= 32
@@ -359,6 +396,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
                 ml[sIdx] = (h16)(1.0f / (1.0f + __expf(-lo[3])));
             }
         }
+        HM_STAMP();   // value head done
         // ---- policy heads: shared 3x3 conv C -> C (+bias, ReLU) into Ss, then 3x3 C -> 146 (two boards)
         for (int i = tid; i < ldx; i += 256) Ss[64 * ldx + i] = (h16)0.0f;
         {
@@ -379,6 +417,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
             }
         }
         __syncthreads();
+        HM_STAMP();   // policy trunk done
         {
             // 146 output planes padded to 160 = 5 channel tiles x 2 square tiles = 10 tiles over 4 waves
             for (int t = wave; t < 10; t += 4) {
@@ -394,17 +433,21 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
             }
         }
         __syncthreads();
+        HM_STAMP();   // projection done
     }
+#undef HM_STAMP
 }
 
 }  // namespace hmn
 
 extern "C" {
+static int net_forward_impl(const int32_t*, size_t, const void*, const void*, const void*, int, void*, void*, void*, void*, void*, void*, unsigned long long*);
 
 // desc: hmn::NetDesc as a flat int32 array (see hivemind_amd/net.py FusedNet); wh / wf: packed fp16 /
 // fp32 parameter buffers (device); planes: fp16 [n,74,8,8]; heads as in hm_sp_process.
-int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
-                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
+static int net_forward_impl(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                            void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream,
+                            unsigned long long* d_dbg) {
     using namespace hmn;
     if (!desc || desc_ints * 4 != sizeof(NetDesc)) return hm_fail(HM_ERR_INVALID, "bad network descriptor size");
     if (n <= 0) return 0;
@@ -412,8 +455,15 @@ int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, cons
     memcpy(&nd, desc, sizeof nd);
     if (nd.C % 64 || nd.nblocks > MAXB || nd.cv > 32) return hm_fail(HM_ERR_INVALID, "unsupported network geometry");
     const size_t ldx = nd.C + 8;
-    const size_t lds = (2 * 65 * ldx + 64 * 66 + 64 * 72) * 2 + 2 * nd.C * 4;
+    size_t lds = (2 * 65 * ldx + 64 * 66 + 64 * 72) * 2 + 2 * nd.C * 4;
     if (lds > 160 * 1024) return hm_fail(HM_ERR_INVALID, "network too wide for one LDS tile");
+    size_t stage = 0;
+    for (int i = 0; i < nd.nblocks; ++i) {
+        const size_t need = (size_t)nd.blk[i].cop * 8 + (size_t)nd.C * 4 + (size_t)nd.blk[i].cop * nd.blk[i].k * nd.blk[i].k * 2;
+        if (need > stage) stage = need;
+    }
+    stage = (stage + 15) & ~(size_t)15;
+    if (lds + stage <= 80 * 1024) lds += stage; else stage = 0;     // only while two workgroups still fit per CU
     hipStream_t st = static_cast<hipStream_t>(stream);
     // device copies of the descriptor: a small ring, re-uploaded (stream-ordered) only when the content changes
     static NetDesc* d_ring = nullptr;
@@ -435,8 +485,8 @@ int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, cons
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
-                           static_cast<const h16*>(d_planes), n, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
-                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left));
+                           static_cast<const h16*>(d_planes), n, (int)stage, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
+                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left), d_dbg);
         return hipGetLastError();
     };
     bool k5 = false;
@@ -454,6 +504,17 @@ int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, cons
     }
     if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));
     return 0;
+}
+
+int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
+    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+}
+// diagnostic build of the same launch: d_stamps[256] receives s_memtime at the phase boundaries of workgroup 0
+int hm_net_profile(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_stamps) {
+    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream,
+                            reinterpret_cast<unsigned long long*>(d_stamps));
 }
 
 }  // extern "C"

@@ -225,6 +225,11 @@ int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_k
 int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
 
+/* Diagnostic variant: same launch, d_stamps[256] (device u64) receives the shader clock at the phase
+ * boundaries of workgroup 0 (tools/profile_net.py). */
+int hm_net_profile(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                   void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_stamps);
+
 /* ================================================================== */
 /* self-play driver: run_selfplay (tools/selfplay.h:10-33,              */
 /* tools/selfplay.cc:558-748) for `concurrent_games` slots on one GPU.  */
