@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhivemind_amd.so")
+# HIVEMIND_AMD_LIB selects another build of the SAME HIP library (e.g. the -DHM_SEARCH_PROF diagnostic build)
+LIB_PATH = os.environ.get("HIVEMIND_AMD_LIB") or os.path.join(_HERE, "csrc", "libhivemind_amd.so")
 
 POS_DTYPE = np.dtype([
     ("by_type", "<u8", (6,)), ("by_color", "<u8", (2,)), ("promoted", "<u8"), ("key", "<u8"),
@@ -51,6 +52,7 @@ _SIGS = {
     "hm_make_moves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "hm_perft": (_i, [_vp, _i, _i, _i, _u64p, C.POINTER(C.c_double)]),
     "hm_net_forward": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_forward_groups": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hm_net_profile": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():

@@ -103,8 +103,31 @@ struct P {                 // register view of hm_pos
     u32 hand[2];           // 5 x 6-bit counts per colour: bits 6*(pt-1)
     u32 castling, ep, stm, rule50, ply;
 };
-__device__ __forceinline__ int hand_get(const P& p, int c, int pt) { return (p.hand[c] >> (6 * (pt - 1))) & 63; }
-__device__ __forceinline__ void hand_add(P& p, int c, int pt, int d) { p.hand[c] += (u32)d << (6 * (pt - 1)); }
+// P must stay in registers: every runtime-indexed access goes through these select helpers (a
+// runtime subscript on a member array would demote the whole struct to scratch memory).
+__device__ __forceinline__ u64 bc_of(const P& p, int c) { return c ? p.bc[1] : p.bc[0]; }
+__device__ __forceinline__ void bc_xor(P& p, int c, u64 m) { p.bc[0] ^= c ? 0ULL : m; p.bc[1] ^= c ? m : 0ULL; }
+__device__ __forceinline__ void bt_xor(P& p, int idx, u64 m) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.bt[i] ^= i == idx ? m : 0ULL;
+}
+__device__ __forceinline__ int hand_get(const P& p, int c, int pt) { return ((c ? p.hand[1] : p.hand[0]) >> (6 * (pt - 1))) & 63; }
+__device__ __forceinline__ void hand_add(P& p, int c, int pt, int d) {
+    const u32 v = (u32)d << (6 * (pt - 1));
+    p.hand[0] += c ? 0u : v; p.hand[1] += c ? v : 0u;
+}
+__device__ __forceinline__ P pick_pos(const P* bd, int b) {      // bd[b] without a runtime subscript
+    P r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.bt[i] = b ? bd[1].bt[i] : bd[0].bt[i];
+    r.bc[0] = b ? bd[1].bc[0] : bd[0].bc[0]; r.bc[1] = b ? bd[1].bc[1] : bd[0].bc[1];
+    r.promoted = b ? bd[1].promoted : bd[0].promoted; r.key = b ? bd[1].key : bd[0].key;
+    r.hand[0] = b ? bd[1].hand[0] : bd[0].hand[0]; r.hand[1] = b ? bd[1].hand[1] : bd[0].hand[1];
+    r.castling = b ? bd[1].castling : bd[0].castling; r.ep = b ? bd[1].ep : bd[0].ep; r.stm = b ? bd[1].stm : bd[0].stm;
+    r.rule50 = b ? bd[1].rule50 : bd[0].rule50; r.ply = b ? bd[1].ply : bd[0].ply;
+    return r;
+}
+__device__ __forceinline__ void put_pos(P* bd, int b, const P& x) { if (b) bd[1] = x; else bd[0] = x; }
 
 __device__ __forceinline__ void load_pos(P& p, const hm_pos* g) {
     const u64* w = reinterpret_cast<const u64*>(g);
@@ -157,7 +180,7 @@ __device__ __forceinline__ int piece_type_on(const P& p, int s) {   // 0 none, 1
 
 // attackers_to (position.cpp:845-855, fastAttacks)
 __device__ __forceinline__ u64 attackers_to(const AttackTab& t, const P& p, int s, u64 occ, int c) {
-    u64 by = p.bc[c];
+    u64 by = bc_of(p, c);
     return ((t.pawn[c ^ 1][s] & p.bt[0]) | (t.knight[s] & p.bt[1]) | (t.king[s] & p.bt[5])
             | (rook_att(s, occ) & (p.bt[3] | p.bt[4])) | (bishop_att(t, s, occ) & (p.bt[2] | p.bt[4]))) & by;
 }
@@ -170,31 +193,31 @@ struct Analysis {
 __device__ __forceinline__ void analyse(const AttackTab& t, const P& p, Analysis& a) {
     const int us = p.stm, them = us ^ 1;
     const u64 occ = occ_of(p);
-    const u64 kbb = p.bt[5] & p.bc[us];
+    const u64 kbb = p.bt[5] & bc_of(p, us);
     const int k = lsb(kbb);
     a.ksq = k;
     a.checkers = attackers_to(t, p, k, occ, them);
     // pinned: snipers on an otherwise empty board, exactly one piece (ours) between
-    u64 snipers = ((rook_att(k, 0) & (p.bt[3] | p.bt[4])) | (bishop_att(t, k, 0) & (p.bt[2] | p.bt[4]))) & p.bc[them];
+    u64 snipers = ((rook_att(k, 0) & (p.bt[3] | p.bt[4])) | (bishop_att(t, k, 0) & (p.bt[2] | p.bt[4]))) & bc_of(p, them);
     u64 pinned = 0;
     while (snipers) {
         int s = pop_lsb(snipers);
         u64 b = between_incl(t, k, s) & ~bit(s) & occ;
-        if (b && !(b & (b - 1)) && (b & p.bc[us])) pinned |= b;
+        if (b && !(b & (b - 1)) && (b & bc_of(p, us))) pinned |= b;
     }
     a.pinned = pinned;
     // danger: squares attacked by `them` with our king lifted off the board
     const u64 o2 = occ ^ kbb;
-    const u64 tp = p.bt[0] & p.bc[them];
+    const u64 tp = p.bt[0] & bc_of(p, them);
     u64 d = them == 0 ? (((tp & ~FILE_A) << 7) | ((tp & ~FILE_H) << 9))
                       : (((tp & ~FILE_H) >> 7) | ((tp & ~FILE_A) >> 9));
-    u64 b = p.bt[1] & p.bc[them];
+    u64 b = p.bt[1] & bc_of(p, them);
     while (b) d |= t.knight[pop_lsb(b)];
-    b = (p.bt[2] | p.bt[4]) & p.bc[them];
+    b = (p.bt[2] | p.bt[4]) & bc_of(p, them);
     while (b) d |= bishop_att(t, pop_lsb(b), o2);
-    b = (p.bt[3] | p.bt[4]) & p.bc[them];
+    b = (p.bt[3] | p.bt[4]) & bc_of(p, them);
     while (b) d |= rook_att(pop_lsb(b), o2);
-    d |= t.king[lsb(p.bt[5] & p.bc[them])];
+    d |= t.king[lsb(p.bt[5] & bc_of(p, them))];
     a.danger = d;
 }
 
@@ -218,7 +241,7 @@ __device__ inline int gen_legal(const AttackTab& t, const P& p, u32* out) {
     Analysis an;
     analyse(t, p, an);
     const int us = p.stm, them = us ^ 1, k = an.ksq;
-    const u64 occ = occ_of(p), ours = p.bc[us], theirs = p.bc[them];
+    const u64 occ = occ_of(p), ours = bc_of(p, us), theirs = bc_of(p, them);
     const bool evasion = an.checkers != 0;
     int n = 0;
     auto pin_ok = [&](int from, int to) -> u32 {
@@ -348,7 +371,7 @@ __device__ inline int count_legal(const AttackTab& t, const P& p) {
     Analysis an;
     analyse(t, p, an);
     const int us = p.stm, them = us ^ 1, k = an.ksq;
-    const u64 occ = occ_of(p), ours = p.bc[us], theirs = p.bc[them];
+    const u64 occ = occ_of(p), ours = bc_of(p, us), theirs = bc_of(p, them);
     const bool evasion = an.checkers != 0;
     int n = popc(t.king[k] & ~ours & ~an.danger);
     if (evasion && (an.checkers & (an.checkers - 1))) return n;
@@ -444,7 +467,7 @@ __device__ inline int do_move(const AttackTab& t, const ZobristTab& z, P& p, u32
         const int rto = base + (ks ? 5 : 3), kto = base + (ks ? 6 : 2);
         p.bt[5] ^= fb | bit(kto);
         p.bt[3] ^= tb | bit(rto);
-        p.bc[us] ^= fb | bit(kto) | tb | bit(rto);
+        bc_xor(p, us, fb | bit(kto) | tb | bit(rto));
         k ^= z.psq[us][3][to] ^ z.psq[us][3][rto] ^ z.psq[us][5][from] ^ z.psq[us][5][kto];
     } else {
         int cap = 0, capsq = to;
@@ -453,7 +476,7 @@ __device__ inline int do_move(const AttackTab& t, const ZobristTab& z, P& p, u32
         if (cap) {
             const u64 cb = bit(capsq);
             const bool capProm = (p.promoted & cb) != 0;
-            p.bt[cap - 1] ^= cb; p.bc[them] ^= cb; p.promoted &= ~cb;
+            bt_xor(p, cap - 1, cb); bc_xor(p, them, cb); p.promoted &= ~cb;
             toHand = (them << 3) | (capProm ? 1 : cap);
             k ^= z.psq[them][cap - 1][capsq];
             p.rule50 = 0;
@@ -461,11 +484,11 @@ __device__ inline int do_move(const AttackTab& t, const ZobristTab& z, P& p, u32
         if (mt == HM_MT_DROP) {
             int h = hand_get(p, us, pt);
             k ^= z.psq[us][pt - 1][to] ^ z.in_hand[us][pt - 1][h - 1] ^ z.in_hand[us][pt - 1][h];
-            p.bt[pt - 1] |= tb; p.bc[us] |= tb;
+            bt_xor(p, pt - 1, tb); bc_xor(p, us, tb);
             hand_add(p, us, pt, -1);
         } else {
             k ^= z.psq[us][pt - 1][from] ^ z.psq[us][pt - 1][to];
-            p.bt[pt - 1] ^= fb | tb; p.bc[us] ^= fb | tb;
+            bt_xor(p, pt - 1, fb | tb); bc_xor(p, us, fb | tb);
             if (p.promoted & fb) p.promoted ^= fb | tb;
         }
     }
@@ -485,12 +508,12 @@ __device__ inline int do_move(const AttackTab& t, const ZobristTab& z, P& p, u32
     if (pt == 1) {
         const int push = us == 0 ? 8 : -8;
         int d = to - from; d = d < 0 ? -d : d;
-        if (mt != HM_MT_DROP && d == 16 && (t.pawn[us][to - push] & p.bt[0] & p.bc[them])) {
+        if (mt != HM_MT_DROP && d == 16 && (t.pawn[us][to - push] & p.bt[0] & bc_of(p, them))) {
             p.ep = (u32)(to - push);
             k ^= z.ep[p.ep & 7];
         } else if (mt == HM_MT_PROMOTION) {
             const int pr = (m >> 16) & 63;
-            p.bt[0] ^= tb; p.bt[pr - 1] |= tb; p.promoted |= tb;
+            p.bt[0] ^= tb; bt_xor(p, pr - 1, tb); p.promoted |= tb;
             k ^= z.psq[us][0][to] ^ z.psq[us][pr - 1][to];
         }
         p.rule50 = 0;

@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
                                                            const h16* __restrict__ planes, int n, int stageBytes,
                                                            h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
                                                            h16* __restrict__ wdl, h16* __restrict__ ml,
+                                                           const int* __restrict__ groupRows, int group,
                                                            unsigned long long* __restrict__ dbg) {
     // diagnostic stamps (dbg != nullptr only from hm_net_profile): cycle counter at phase boundaries of block 0
     int dbgN = 0;
@@ -230,6 +231,8 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
+        // rows beyond a group's live count carry no position this step (uniform per workgroup)
+        if (groupRows && (sIdx % group) >= groupRows[sIdx / group]) continue;
         HM_STAMP();   // 0: start
         // ---- input planes: NCHW [74][64] fp16 -> Ss as [sq][cin_pad] (+ zero row 64)
         const int ldi = nd.cin_pad + 8;
@@ -441,16 +444,17 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
 }  // namespace hmn
 
 extern "C" {
-static int net_forward_impl(const int32_t*, size_t, const void*, const void*, const void*, int, void*, void*, void*, void*, void*, void*, unsigned long long*);
+static int net_forward_impl(const int32_t*, size_t, const void*, const void*, const void*, int, const int32_t*, int, void*, void*, void*, void*, void*, void*, unsigned long long*);
 
 // desc: hmn::NetDesc as a flat int32 array (see hivemind_amd/net.py FusedNet); wh / wf: packed fp16 /
 // fp32 parameter buffers (device); planes: fp16 [n,74,8,8]; heads as in hm_sp_process.
 static int net_forward_impl(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
-                            void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream,
+                            const int32_t* d_group_rows, int group, void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream,
                             unsigned long long* d_dbg) {
     using namespace hmn;
     if (!desc || desc_ints * 4 != sizeof(NetDesc)) return hm_fail(HM_ERR_INVALID, "bad network descriptor size");
     if (n <= 0) return 0;
+    if (d_group_rows && group <= 0) return hm_fail(HM_ERR_INVALID, "group size must be positive");
     NetDesc nd;
     memcpy(&nd, desc, sizeof nd);
     if (nd.C % 64 || nd.nblocks > MAXB || nd.cv > 32) return hm_fail(HM_ERR_INVALID, "unsupported network geometry");
@@ -486,7 +490,8 @@ static int net_forward_impl(const int32_t* desc, size_t desc_ints, const void* d
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
                            static_cast<const h16*>(d_planes), n, (int)stage, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
-                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left), d_dbg);
+                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
+                           reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
         return hipGetLastError();
     };
     bool k5 = false;
@@ -508,12 +513,20 @@ static int net_forward_impl(const int32_t* desc, size_t desc_ints, const void* d
 
 int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
-    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+}
+// Ragged batches: rows are grouped (`group` consecutive rows per game slot) and only the first d_group_rows[g]
+// rows of group g hold a position; the other rows are skipped and their head outputs are left untouched
+// (the reference hands TensorRT exactly batchSize rows per search thread, searchthread.cc:474-484).
+int hm_net_forward_groups(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                          const int32_t* d_group_rows, int group,
+                          void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
+    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_group_rows, group, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
 }
 // diagnostic build of the same launch: d_stamps[256] receives s_memtime at the phase boundaries of workgroup 0
 int hm_net_profile(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_stamps) {
-    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream,
+    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream,
                             reinterpret_cast<unsigned long long*>(d_stamps));
 }
 

@@ -87,7 +87,7 @@ __device__ inline bool is_draw_on_board(const P& p, const Hist& h, int ply) {   
 }
 
 __device__ __forceinline__ u64 checkers_of(const AttackTab& t, const P& p) {
-    return attackers_to(t, p, lsb(p.bt[5] & p.bc[p.stm]), occ_of(p), p.stm ^ 1);
+    return attackers_to(t, p, lsb(p.bt[5] & bc_of(p, p.stm)), occ_of(p), p.stm ^ 1);
 }
 __device__ __forceinline__ bool is_capture(const P& p, u32 m) {   // position.h:1212-1216
     const u32 mt = m & (15u << 12);
@@ -126,7 +126,7 @@ __device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, con
     const bool partnerTurn = (int)bd[pb].stm == partnerSide;
     if (!partnerTurn && !adv) return false;
     const P& p = bd[boardInCheck];
-    const int k = lsb(p.bt[5] & p.bc[checkedSide]);
+    const int k = lsb(p.bt[5] & bc_of(p, checkedSide));
     const u64 chk = checkers_of(t.att, p);
     if (chk & (chk - 1)) return false;
     const int csq = lsb(chk);

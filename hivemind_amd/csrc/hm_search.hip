@@ -139,6 +139,15 @@ struct Pools {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
+// Diagnostic cycle accounting of game slot 0 (build with -DHM_SEARCH_PROF; read with hm_sp_profile).
+__device__ unsigned long long g_prof[32];
+#ifdef HM_SEARCH_PROF
+#define PROF_T(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
+#define PROF_ADD(slot, t) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[slot] += __builtin_amdgcn_s_memtime() - (t); g_prof[16 + (slot)]++; } } while (0)
+#else
+#define PROF_T(t) do {} while (0)
+#define PROF_ADD(slot, t) do {} while (0)
+#endif
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -583,11 +592,17 @@ __device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajE
         }
         if (p.len >= MAX_TRAJ - 1) { s.g->overflow |= 4; return -1; }
         int next = -1, childIdx = -1;
-        if (should_expand_new_child(s, n)) {
+        PROF_T(tw);
+        const bool widen = should_expand_new_child(s, n);
+        PROF_ADD(1, tw);
+        if (widen) {
             // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
             GenHdr* gh = gen_of(s, n);
             HeapEnt he;
-            if (gen_next(s, *gh, &he)) {
+            PROF_T(tg);
+            const bool got = gen_next(s, *gh, &he);
+            PROF_ADD(2, tg);
+            if (got) {
                 u32 ma, mb;
                 const float jp = joint_prior(s, *gh, he.iA, he.iB, &ma, &mb);
                 const int child = node_alloc(s, n.team ^ 1, n.depth + 1);
@@ -601,9 +616,13 @@ __device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajE
                     nn.expanded++;
                     next = child;
                     bool childReserved = true;
+                    PROF_T(tm);
                     jb_make(rt, p.jb, ma, mb, true);
+                    PROF_ADD(4, tm);
                     int pend = -1;
+                    PROF_T(tc);
                     const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, childReserved, rootAdv, rootTeam, &pend);
+                    PROF_ADD(5, tc);
                     if (cr == 2) return -1;
                     traj[p.len - 1].childIdx = childIdx;
                     traj[p.len] = TrajEnt{next, -1, ma, mb};
@@ -615,13 +634,19 @@ __device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajE
                 return -1;                                    // pool exhausted (overflow flagged)
             }
         }
+        PROF_T(ts);
         const Sel sel = select_child_and_apply_virtual_loss(s, cur, unavailMask);
+        PROF_ADD(3, ts);
         if (sel.child < 0 || sel.idx < 0) return -1;
         next = sel.child; childIdx = sel.idx; reserved = sel.reserved;
         const Edge ed = edges_of(s, s.nodes[cur])[childIdx];
+        PROF_T(tm);
         jb_make(rt, p.jb, ed.moveA, ed.moveB, true);
+        PROF_ADD(4, tm);
         int pend = -1;
+        PROF_T(tc);
         const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, reserved, rootAdv, rootTeam, &pend);
+        PROF_ADD(5, tc);
         if (cr == 2) return -1;
         traj[p.len - 1].childIdx = childIdx;
         traj[p.len] = TrajEnt{next, -1, ed.moveA, ed.moveB};
@@ -695,8 +720,10 @@ struct ExpLds {          // per-wave scratch of expand_leaf
     float priors[2][HM_MAX_MOVES + 8];
 };
 struct WaveLds {
-    u32 lists[NLISTS][HM_MAX_MOVES];
-    ExpLds exp;
+    union {                  // expand_leaf scratch aliases lists[0..4]: never live together (k_raw_policy uses lists[0..1] == exp.lists)
+        u32 lists[NLISTS][HM_MAX_MOVES];
+        ExpLds exp;
+    };
     u64 board[26];
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
@@ -959,9 +986,11 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
     Path p;
     while (nctx < BATCH && attempts < BATCH * 2) {
         attempts++;
+        PROF_T(t0);
         path_reset(s, p);
         bool reserved = false;
         const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
+        PROF_ADD(0, t0);
         if (leaf < 0) {
             s.g->reservationCollisions++;
             cancel_virtual_losses(s, L.traj, p.len);
@@ -990,7 +1019,9 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
             ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
         } else {
             int endInPly = 0;
+            PROF_T(tk);
             const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
+            PROF_ADD(6, tk);
             if (to != 0) {
                 ctx.terminal = 1;
                 Node& ln = s.nodes[leaf];
@@ -1003,6 +1034,7 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
                 keep = false;
             } else {
                 const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
+                PROF_T(tp);
                 ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
                 store_pos(&ctx.pos[0], p.jb.bd[0]);
                 store_pos(&ctx.pos[1], p.jb.bd[1]);
@@ -1021,15 +1053,18 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
                 }
                 wave_fence();
                 write_planes_f16(rt, L.board, reinterpret_cast<uint4*>(planesOut + (size_t)valid * HM_PLANE_VALUES), L.pmask, L.pval);
+                PROF_ADD(7, tp);
                 valid++;
             }
         }
         if (keep) {
+            PROF_T(tx);
             s.ctx[buf * BATCH + nctx] = ctx;
             TrajEnt* dst = s.traj + (size_t)(buf * BATCH + nctx) * MAX_TRAJ;
             for (int i = lane; i < p.len; i += 64) dst[i] = L.traj[i];
             wave_fence();
             nctx++;
+            PROF_ADD(8, tx);
         }
     }
     s.g->ctxCount[buf] = nctx;
@@ -1046,23 +1081,25 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
 // searchthread.cc:680-688).  A game with no batch in flight collects its first batch into NEXT and
 // marks it `fresh`; its lookahead follows one iteration later (same order of tree operations as
 // run_iteration: collect b0, collect b1, process b0).  Runs on one wave.
-__device__ inline void collect_step(G& s, const RulesTab& rt, WaveLds& L, uint16_t* planesNext, int g) {
-    if (s.g->status != ST_SEARCHING) return;
+__device__ inline int collect_step(G& s, const RulesTab& rt, WaveLds& L, uint16_t* planesNext, int g) {   // returns the plane rows written
+    if (s.g->status != ST_SEARCHING) return 0;
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
     uint16_t* nxt = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
     // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
     while (s.g->pending < 0) {
-        if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
+        if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return 0; }
         collect_batch(s, rt, L, 0, rootTeam, rootAdv, nxt);
-        if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return; }   // no progress possible
+        if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return 0; }   // no progress possible
         if (s.g->validCount[0] == 0) { process_batch(s, rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
         s.g->pending = 0;
         s.g->fresh = 1;
-        return;
+        return s.g->validCount[0];
     }
-    if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return; }
-    collect_batch(s, rt, L, 1 - s.g->pending, rootTeam, rootAdv, nxt);
+    if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return 0; }
+    const int look = 1 - s.g->pending;
+    collect_batch(s, rt, L, look, rootTeam, rootAdv, nxt);
+    return s.g->validCount[look];
 }
 
 // One lockstep iteration, process side, for a block of BATCH waves.  Returns on every wave; only
@@ -1084,9 +1121,11 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
     const bool solvedOrOverflow = s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow;
     const bool doProcess = pending >= 0 && !(st == ST_FINISHING && solvedOrOverflow);
     // phase A: one leaf expansion per wave
+    PROF_T(te);
     if (doProcess && wave < s.g->ctxCount[pending]) expand_context(s, rt, exp[wave], pending, wave, rootTeam, rootAdv, &out, rowBase);
     __threadfence_block();
     __syncthreads();
+    PROF_ADD(11, te);
     if (wave == 0) {
         // phase B (wave 0): ordered backups and the run_iteration / finish_pending tail
         if (st == ST_FINISHING) {
@@ -1110,16 +1149,21 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
     }
     __threadfence_block();
     __syncthreads();
+    PROF_ADD(12, te);
 }
 
-__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* activeCount) {
+__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
+    PROF_T(ta);
     stage_table(&s_rt, pl.rules);
     __syncthreads();
+    PROF_ADD(9, ta);
     G s = make_view(pl, prm, blockIdx.x);
-    collect_step(s, s_rt, L, planesNext, blockIdx.x);
+    const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
+    if (rowsNext && threadIdx.x == 0) rowsNext[blockIdx.x] = rows;     // batch size of this game for the evaluator
+    PROF_ADD(10, ta);
 }
 
 __global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
@@ -1147,7 +1191,7 @@ __global__ __launch_bounds__(64 * BATCH) void k_step(Pools pl, Params prm, NetOu
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, L.exp, out, blockIdx.x, activeCount + parity);
     if ((threadIdx.x >> 6) != 0) return;
-    collect_step(s, s_rt, L.wave, planesNext, blockIdx.x);
+    (void)collect_step(s, s_rt, L.wave, planesNext, blockIdx.x);
 }
 
 // Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
@@ -1158,7 +1202,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
-    if (searchMask && !searchMask[g]) { s.g->status = ST_IDLE; rootHashOut[g] = 0; return; }
+    if (searchMask && !searchMask[g]) { s.g->status = ST_IDLE; rootHashOut[2 * g] = 0; rootHashOut[2 * g + 1] = 0; return; }
     const RulesTab& rt = s_rt;
     for (int i = lane; i < prm.ttCap; i += 64) s.ttVals[i] = -1;
     wave_fence();
@@ -1178,7 +1222,8 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     const bool canWait = is_double_sit_legal(adv, aOn, bOn);
     const u64 rootHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), adv, rt.zob.time_adv);
     gm.rootHash = rootHash;
-    rootHashOut[g] = rootHash;
+    rootHashOut[2 * g] = rootHash;
+    rootHashOut[2 * g + 1] = 0;              // (legal moves + pass) per board, for the host's Dirichlet draws
     const bool mateUs = is_checkmate(rt, p.jb.bd, team, adv, scratch);
     if (is_checkmate(rt, p.jb.bd, team ^ 1, !adv, scratch) || mateUs || jb_is_draw(p.jb, 0)) { gm.status = ST_NOACTION; return; }
     const int cA = aOn ? count_legal(rt.att, p.jb.bd[0]) : 0, cB = bOn ? count_legal(rt.att, p.jb.bd[1]) : 0;
@@ -1198,6 +1243,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         if (lane == 0 && aOn) nA = gen_legal(rt.att, p.jb.bd[0], la);
         if (lane == 1 && bOn) nB = gen_legal(rt.att, p.jb.bd[1], lb);
         nA = __shfl(nA, 0); nB = __shfl(nB, 1);
+        rootHashOut[2 * g + 1] = (u64)(u32)(nA + 1) | ((u64)(u32)(nB + 1) << 32);
         __builtin_amdgcn_wave_barrier();
         const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;
         for (int i = lane; i < nA; i += 64) flA[i] = (gives_check(rt, p.jb.bd[0], la[i]) ? 1u : 0u) | (is_capture(p.jb.bd[0], la[i]) ? 2u : 0u);
@@ -1659,13 +1705,13 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * 12);
-    rc |= dalloc(sp, &sp->d_rootHash, G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_active2, 2); rc |= dalloc(sp, &sp->d_target, G_);
+    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_active2, 2); rc |= dalloc(sp, &sp->d_target, G_);
     rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
     rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
     rc |= dalloc(sp, &sp->raw.caps, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.counts, G_ * 2); rc |= dalloc(sp, &sp->raw.onTurn, G_ * 2);
     if (rc) { hm_sp_destroy(sp); return rc; }
-    sp->h_rootHash.resize(G_);
+    sp->h_rootHash.resize(2 * G_);
     *out = sp;
     return 0;
 }
@@ -1694,10 +1740,14 @@ static void fill_noise(hm_sp* sp, const uint64_t* seeds, float alpha, std::vecto
     static const uint64_t salts[2] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL};
     for (int g = 0; g < sp->nGames; ++g)
         for (int b = 0; b < 2; ++b) {
-            std::mt19937_64 eng(seeds[g] ^ sp->h_rootHash[g] ^ salts[b]);
+            // one draw per root action of this board (node.h:286-315); a single action takes no noise
+            int n = (int)((sp->h_rootHash[2 * g + 1] >> (32 * b)) & 0xffffffffu);
+            if (n <= 1) continue;
+            if (n > NOISE_CAP) n = NOISE_CAP;
+            std::mt19937_64 eng(seeds[g] ^ sp->h_rootHash[2 * g] ^ salts[b]);
             std::gamma_distribution<float> gamma(alpha, 1.0f);
             float* dst = buf.data() + ((size_t)g * 2 + b) * NOISE_CAP;
-            for (int i = 0; i < NOISE_CAP; ++i) dst[i] = gamma(eng);
+            for (int i = 0; i < n; ++i) dst[i] = gamma(eng);
         }
 }
 
@@ -1711,7 +1761,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
     if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_begin, dim3(G_), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, alpha, eps, mask ? sp->d_mask : nullptr, sp->d_rootHash);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(sp->h_rootHash.data(), sp->d_rootHash, 8 * (size_t)G_, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sp->h_rootHash.data(), sp->d_rootHash, 16 * (size_t)G_, hipMemcpyDeviceToHost));
     if (alpha > 0.0f && eps > 0.0f) {
         std::vector<float> nz;
         fill_noise(sp, seeds.data(), alpha, nz);
@@ -1721,13 +1771,14 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
     return 0;
 }
 
-int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream) {
+int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
-                       static_cast<uint16_t*>(d_planes_next), sp->d_active);
+                       static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
 }
+int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream) { return hm_sp_collect_counted(sp, d_planes_next, nullptr, stream); }
 
 int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
                   int* active_games, void* stream) {
@@ -1761,6 +1812,13 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+
+// diagnostic (all zeros unless built with -DHM_SEARCH_PROF): out[0..15] cycles, out[16..31] counts; reset != 0 clears
+int hm_sp_profile(unsigned long long* out32, int reset) {
+    if (out32) HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32));
+    if (reset) { unsigned long long z[32] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
+    return HM_OK;
+}
 // fused process(previous heads) + collect(next planes); counts active games into d_active2[parity]
 int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
                void* d_planes_next, int parity, hipStream_t stream) {

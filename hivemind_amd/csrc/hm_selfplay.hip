@@ -115,9 +115,10 @@ struct hm_selfplay {
     hm_board* d_boards = nullptr;
     uint8_t* d_u8 = nullptr;
     std::vector<uint64_t> termCounts = std::vector<uint64_t>(5, 0);
-    std::vector<hipEvent_t> evs;                 // ring of per-iteration leg events
+    std::vector<hipEvent_t> evs, sync;                 // ring of per-iteration leg events
     hipStream_t sT = nullptr, sN = nullptr;      // tree / network streams (native evaluator mode)
     int* hActive = nullptr;
+    int32_t* d_rows[2] = {nullptr, nullptr};   // per game slot: plane rows written into planes[k] (ragged evaluator batch)
 };
 
 static bool start_game(hm_selfplay* s, Slot& sl, hm_board& out) {
@@ -189,14 +190,38 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     if (s->evs.empty()) {
         s->evs.resize((size_t)RING * 6);
         for (auto& e : s->evs) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
+        s->sync.resize((size_t)RING * 2);          // ordering-only events (no timestamps): forward done, process done
+        for (auto& e : s->sync) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
     }
     if (native && !s->sT) {
+        // measured alternative: HM_SELFPLAY_CU_SPLIT=<n> pins the tree stream to n CUs and the network stream to the rest
+        const int split = std::getenv("HM_SELFPLAY_CU_SPLIT") ? std::atoi(std::getenv("HM_SELFPLAY_CU_SPLIT")) : 0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (split > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && split < prop.multiProcessorCount) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> mT(words, 0), mN(words, 0);
+            const int stride = ncu / split;
+            for (int i = 0; i < ncu; ++i) {
+                const bool tree = (i % stride) == 0 && (i / stride) < split;
+                (tree ? mT : mN)[i >> 5] |= 1u << (i & 31);
+            }
+            if (hipExtStreamCreateWithCUMask(&s->sT, words, mT.data()) != hipSuccess || hipExtStreamCreateWithCUMask(&s->sN, words, mN.data()) != hipSuccess)
+                return hm_fail(HM_ERR_NO_DEVICE, "hipExtStreamCreateWithCUMask failed");
+        } else {
         if (hipStreamCreateWithFlags(&s->sT, hipStreamNonBlocking) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
         if (std::getenv("HM_SELFPLAY_SEQUENTIAL")) s->sN = s->sT;          // diagnostic: no collect/net overlap
         else if (hipStreamCreateWithFlags(&s->sN, hipStreamNonBlocking) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreate failed");
+        }
         if (hipHostMalloc(reinterpret_cast<void**>(&s->hActive), sizeof(int), hipHostMallocDefault) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed");
     }
-    if (native) (void)hipDeviceSynchronize();      // the prologue ran on the null stream
+    static const bool allRows = std::getenv("HM_SELFPLAY_ALL_ROWS") != nullptr;   // diagnostic: evaluate the unused rows too
+    if (native) {
+        (void)hipMemsetAsync(s->d_rows[0], 0, sizeof(int32_t) * s->G, nullptr);      // nothing collected yet for this search
+        (void)hipMemsetAsync(s->d_rows[1], 0, sizeof(int32_t) * s->G, nullptr);
+        (void)hipDeviceSynchronize();              // the prologue ran on the null stream
+    }
     // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
     const int noPollBefore = minTarget / 8 - 1;
@@ -216,6 +241,8 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     while (active > 0) {
         hipEvent_t* e = &s->evs[(size_t)(iters % RING) * 6];
         hipEvent_t* ePrev = &s->evs[(size_t)((iters + RING - 1) % RING) * 6];
+        hipEvent_t* y = &s->sync[(size_t)(iters % RING) * 2];
+        hipEvent_t* yPrev = &s->sync[(size_t)((iters + RING - 1) % RING) * 2];
         const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
         const bool timed = (iters & 7) == 0;       // leg timing is sampled: event records are not free
         if (native && fusedStep) {
@@ -247,21 +274,23 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
                               {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
             void** h = hv[iters & 1];
             if (timed) (void)hipEventRecord(e[0], s->sT);
-            if (int rc = hm_sp_collect(s->sp, s->io.planes[1 - which], s->sT)) return rc;
+            if (int rc = hm_sp_collect_counted(s->sp, s->io.planes[1 - which], s->d_rows[1 - which], s->sT)) return rc;
             if (timed) (void)hipEventRecord(e[1], s->sT);
             // planes[which] were completed by the previous iteration's collect.  The forward could start
             // right after it, but measured on MI355X it then shares CUs with k_process (8-wave blocks,
             // 79 KB LDS), which stretches from 0.12 to 0.33 ms and lengthens the critical path; so the
             // forward is ordered behind process(i-1) and overlaps only collect(i).
-            if (iters > 0) (void)hipStreamWaitEvent(s->sN, ePrev[5], 0);
+            if (iters > 0) (void)hipStreamWaitEvent(s->sN, yPrev[1], 0);
             if (timed) (void)hipEventRecord(e[2], s->sN);
-            if (int rc = hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
-                                        h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
-            (void)hipEventRecord(e[3], s->sN);
-            (void)hipStreamWaitEvent(s->sT, e[3], 0);
+            if (int rc = hm_net_forward_groups(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
+                                               allRows ? nullptr : s->d_rows[which], 8, h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+            if (timed) (void)hipEventRecord(e[3], s->sN);
+            (void)hipEventRecord(y[0], s->sN);
+            (void)hipStreamWaitEvent(s->sT, y[0], 0);
             if (timed) (void)hipEventRecord(e[4], s->sT);
             if (int rc = hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT)) return rc;
-            (void)hipEventRecord(e[5], s->sT);
+            if (timed) (void)hipEventRecord(e[5], s->sT);
+            (void)hipEventRecord(y[1], s->sT);
             if (poll) {
                 if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;     // async copy + stream sync
                 active = *s->hActive;
@@ -319,7 +348,8 @@ int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* sc
     s->runId = c.seed != 0 ? c.seed : static_cast<uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
     const int maxNodes = (int)std::llround((double)c.nodes * (1.0 + c.node_random_factor)) + 1;
     if (int rc = hm_sp_create(s->G, maxNodes, &s->scfg, &s->sp)) { delete s; return rc; }
-    if (hipMalloc(&s->d_boards, sizeof(hm_board) * s->G) != hipSuccess || hipMalloc(&s->d_u8, (size_t)HM_PLANE_VALUES * s->G) != hipSuccess) {
+    if (hipMalloc(&s->d_boards, sizeof(hm_board) * s->G) != hipSuccess || hipMalloc(&s->d_u8, (size_t)HM_PLANE_VALUES * s->G) != hipSuccess
+        || hipMalloc(&s->d_rows[0], sizeof(int32_t) * s->G) != hipSuccess || hipMalloc(&s->d_rows[1], sizeof(int32_t) * s->G) != hipSuccess) {
         hm_sp_destroy(s->sp); delete s; return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed");
     }
     s->slots.resize(s->G);
@@ -332,10 +362,13 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->sp) hm_sp_destroy(s->sp);
     if (s->d_boards) (void)hipFree(s->d_boards);
     if (s->d_u8) (void)hipFree(s->d_u8);
+    if (s->d_rows[0]) (void)hipFree(s->d_rows[0]);
+    if (s->d_rows[1]) (void)hipFree(s->d_rows[1]);
     if (s->sT) (void)hipStreamDestroy(s->sT);
     if (s->sN && s->sN != s->sT) (void)hipStreamDestroy(s->sN);
     if (s->hActive) (void)hipHostFree(s->hActive);
     for (auto& e : s->evs) if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->sync) if (e) (void)hipEventDestroy(e);
     delete s;
     return 0;
 }
@@ -395,6 +428,7 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
         bool anyRaw = false;
         for (int g = 0; g < G; ++g) { Slot& sl = s->slots[g]; anyRaw |= sl.active && sl.rawActive && sl.macroPly < sl.initLength; }
         if (anyRaw) {
+            const auto tr0 = std::chrono::steady_clock::now();
             if (int rc = hm_encode_planes(s->d_boards, G, HM_DT_F16, s->io.planes[0], nullptr)) return rc;
             if (int rc = eval_rows_sync(s, 0, G)) return rc;
             s->res.eval_batches += 1;
@@ -455,6 +489,7 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
                 else { sl.rawPlies++; sl.macroPly++; sl.team ^= 1; sl.adv = !sl.adv; }
             }
             if (int rc = hm_sp_apply(s->sp, actA.data(), actB.data(), movedRaw.data())) return rc;
+            s->res.raw_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
         }
 
         // ---- 3. searched plies (selfplay.cc:645-716)
@@ -471,10 +506,14 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
             target[g] = (int)std::max<size_t>(1, static_cast<size_t>(std::llround(static_cast<double>(c.nodes) * (1.0 + jitter(sl.rng)))));
             seeds[g] = mix_seed(s->runId, sl.gameIndex * c.max_macro_plies + sl.macroPly);
         }
+        const auto tp0 = std::chrono::steady_clock::now();
         if (int rc = hm_sp_begin_search(s->sp, target.data(), seeds.data(), c.dirichlet_alpha, c.dirichlet_epsilon, mask.data())) return rc;
         int minTarget = 1 << 30;
         for (int g = 0; g < G; ++g) if (mask[g] && target[g] < minTarget) minTarget = target[g];
+        const auto ts0 = std::chrono::steady_clock::now();
+        s->res.prologue_seconds += std::chrono::duration<double>(ts0 - tp0).count();
         if (int rc = run_search_lockstep(s, minTarget)) return rc;
+        s->res.search_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
         if (int rc = hm_sp_root_stats(s->sp, counts.data(), mA.data(), mB.data(), visits.data(), nullptr, nullptr, rootQ.data(), info.data(), E)) return rc;
         std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0);
         std::vector<uint8_t> applyMask(G, 0);

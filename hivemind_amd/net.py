@@ -378,14 +378,23 @@ class FusedNet:
                             torch.empty((n, 3), **f), torch.empty(n, **f))
         return self._out[n]
 
-    def __call__(self, planes: torch.Tensor, out=None):
-        """out = (value[n], pi_a[n,4672], pi_b[n,4672], wdl[n,3], moves_left[n]) fp16 tensors to fill in place."""
+    def __call__(self, planes: torch.Tensor, out=None, group_rows=None, group=8):
+        """out = (value[n], pi_a[n,4672], pi_b[n,4672], wdl[n,3], moves_left[n]) fp16 tensors to fill in place.
+        group_rows (int32 CUDA tensor [n / group], from SearchEngine.collect): only the first group_rows[g] rows of
+        each group of `group` rows are evaluated; the other rows' outputs are left as they are."""
         if planes.dtype != torch.float16 or not planes.is_contiguous():
             planes = planes.to(torch.float16).contiguous()
         n = planes.shape[0]
         v, a, b, w, m = out if out is not None else self._buffers(n)
         st = torch.cuda.current_stream().cuda_stream
-        self._check(self._lib.hm_net_forward(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
-                                             planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),
-                                             m.data_ptr(), self._C.c_void_p(st)))
+        if group_rows is None:
+            self._check(self._lib.hm_net_forward(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
+                                                 planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),
+                                                 m.data_ptr(), self._C.c_void_p(st)))
+        else:
+            if group_rows.dtype != torch.int32 or group_rows.numel() * group != n or group_rows.device.type != "cuda":
+                raise ValueError("group_rows must be an int32 CUDA tensor with n / group entries")
+            self._check(self._lib.hm_net_forward_groups(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
+                                                        planes.data_ptr(), n, group_rows.data_ptr(), group, v.data_ptr(), a.data_ptr(),
+                                                        b.data_ptr(), w.data_ptr(), m.data_ptr(), self._C.c_void_p(st)))
         return v, a, b, w, m

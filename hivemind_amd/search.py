@@ -33,6 +33,7 @@ _SIGS = {
     "hm_sp_set_games": (_i, [_vp, _vp, _vp]),
     "hm_sp_begin_search": (_i, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
     "hm_sp_collect": (_i, [_vp, _vp, _vp]),
+    "hm_sp_collect_counted": (_i, [_vp, _vp, _vp, _vp]),
     "hm_sp_process": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp]),
     "hm_sp_max_edges": (_i, [_vp]),
     "hm_sp_active": (_i, [_vp, C.POINTER(_i)]),
@@ -114,9 +115,13 @@ class SearchEngine:
         check(lib.hm_sp_begin_search(self.h, t.ctypes.data, _p(s), float(alpha), float(eps), _p(m)))
         self.cur = 0
 
-    def collect(self):
+    def collect(self, rows_next=None):
+        """Collect the next batch; rows_next (int32 CUDA tensor [G], optional) receives the plane rows each game wrote."""
         st = torch.cuda.current_stream().cuda_stream
-        check(lib.hm_sp_collect(self.h, self.planes[1 - self.cur].data_ptr(), st))
+        if rows_next is None:
+            check(lib.hm_sp_collect(self.h, self.planes[1 - self.cur].data_ptr(), st))
+        else:
+            check(lib.hm_sp_collect_counted(self.h, self.planes[1 - self.cur].data_ptr(), rows_next.data_ptr(), st))
         return self.planes[self.cur]
 
     def process(self, value, pi_a, pi_b, wdl, moves_left, want_active=True) -> int:

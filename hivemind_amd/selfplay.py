@@ -36,7 +36,8 @@ class SelfPlayResult(C.Structure):
                 ("eval_rows", C.c_uint64), ("eval_batches", C.c_uint64), ("search_iterations", C.c_uint64), ("raw_plies", C.c_uint64),
                 ("record_bytes", C.c_uint64), ("terminations", C.c_uint64 * 5), ("seconds", C.c_double),
                 ("collect_ms", C.c_double), ("eval_ms", C.c_double), ("process_ms", C.c_double),
-                ("nodes_visited", C.c_uint64), ("edges_scanned", C.c_uint64)]
+                ("nodes_visited", C.c_uint64), ("edges_scanned", C.c_uint64),
+                ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double)]
 
 
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)

@@ -188,6 +188,9 @@ int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask);
  * node.h:286-315; alpha == 0 disables it. */
 int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask);
 int hm_sp_collect(hm_sp* sp, void* d_planes_next, void* stream);
+/* As hm_sp_collect; additionally d_rows_next[g] (device, n_games ints) = the number of plane rows game g
+ * wrote, i.e. the batchSize its search thread hands to Engine::run (searchthread.cc:474-484). */
+int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream);
 /* active_games (host, optional): number of games still searching after this step (forces a sync). */
 int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl,
                   const void* d_moves_left, int* active_games, void* stream);
@@ -224,6 +227,11 @@ int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_k
 /* ================================================================== */
 int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
+/* Ragged batch: rows come in groups of `group` (one group per game slot); only the first d_group_rows[g]
+ * rows of group g are evaluated (d_group_rows from hm_sp_collect_counted), the rest are skipped. */
+int hm_net_forward_groups(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+                          const int32_t* d_group_rows, int group,
+                          void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
 
 /* Diagnostic variant: same launch, d_stamps[256] (device u64) receives the shader clock at the phase
  * boundaries of workgroup 0 (tools/profile_net.py). */
@@ -277,6 +285,9 @@ typedef struct hm_selfplay_result {
     /* device time of the three legs of a lockstep iteration, HIP events on the launch stream */
     double   collect_ms, eval_ms, process_ms;
     uint64_t nodes_visited, edges_scanned;   /* tree nodes / edges read by selection (roofline accounting) */
+    /* wall-clock split of `seconds`: lockstep search loop, search prologue (hm_sp_begin_search), raw-policy plies;
+     * the remainder is host bookkeeping (terminal checks, record building, root statistics) */
+    double   search_seconds, prologue_seconds, raw_seconds;
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,

@@ -47,3 +47,27 @@ def test_fused_forward_matches_fp32_reference(hm, name):
         sub = fused(planes[:n].contiguous())
         for a, b in zip(sub, got):
             assert torch.equal(a, b[:n])
+
+
+def test_ragged_groups_skip_unused_rows(hm):
+    """hm_net_forward_groups: live rows equal the dense forward bit for bit, skipped rows stay untouched."""
+    import oracle_py as O
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    model = N.rise_v3_small()
+    model.eval()
+    boards = O.random_positions(5, 64, 100)
+    planes = hm.board_to_planes(hm.to_device(boards), "f16")
+    fused = N.FusedNet(model)
+    dense = [t.clone() for t in fused(planes)]
+    counts = torch.tensor([8, 0, 3, 1, 7, 8, 0, 5], dtype=torch.int32, device="cuda")
+    out = tuple(torch.full_like(t, 7.0) for t in dense)
+    fused(planes, out=out, group_rows=counts, group=8)
+    torch.cuda.synchronize()
+    live = torch.zeros(64, dtype=torch.bool)
+    for g, c in enumerate(counts.tolist()):
+        live[g * 8:g * 8 + c] = True
+    live = live.cuda()
+    for d, o in zip(dense, out):
+        assert torch.equal(o[live], d[live])
+        assert bool((o[~live] == 7.0).all())

@@ -74,3 +74,25 @@ def test_search_matches_oracle(hm, nodes, noise):
         exact += 1
     assert exact == G
     eng.close()
+
+
+def test_collect_row_counts(hm):
+    import torch
+    """hm_sp_collect_counted: per-game batch sizes add up to the evaluator rows the search reports."""
+    G = 8
+    roots = _roots(G, 901)
+    eng = hm.SearchEngine(G, 500)
+    eng.set_games(roots)
+    eng.begin_search(200)
+    rows = torch.zeros(G, dtype=torch.int32, device="cuda")
+    total = np.zeros(G, np.int64)
+    for _ in range(2000):
+        planes = eng.collect(rows_next=rows)
+        r = rows.cpu().numpy()
+        assert ((0 <= r) & (r <= 8)).all()
+        total += r
+        if eng.process(*_hash_eval_gpu(planes)) == 0:
+            break
+    st = eng.root_stats()
+    # rows written after a game's last processed batch (aborted lookahead) are counted by collect but not evaluated
+    assert (total >= st["info"][:, 2]).all() and (total - st["info"][:, 2] <= 8).all(), (total, st["info"][:, 2])

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Cycle accounting of k_collect / k_process for game slot 0 (diagnostic build, -DHM_SEARCH_PROF).
+
+Build here:  python tools/profile_search.py --build     (writes hivemind_amd/csrc/libhivemind_amd_prof.so)
+Run on GPU:  HIVEMIND_AMD_LIB=hivemind_amd/csrc/libhivemind_amd_prof.so python tools/profile_search.py
+"""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "hivemind_amd", "csrc", "libhivemind_amd_prof.so")
+if "--build" in sys.argv:
+    src = [os.path.join(ROOT, "hivemind_amd", "csrc", f) for f in ("hm_kernels.hip", "hm_search.hip", "hm_selfplay.hip", "hm_net.hip")]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHM_SEARCH_PROF",
+                           "-I", os.path.join(ROOT, "include"), *src, "-o", PROF])
+    print("built", PROF)
+    sys.exit(0)
+os.environ.setdefault("HIVEMIND_AMD_LIB", PROF)
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import hivemind_amd as hm
+from hivemind_amd import net as N, _lib
+
+games = int(os.environ.get("GAMES", 64)); nodes = int(os.environ.get("NODES", 400))
+hm.init(0)
+torch.manual_seed(0)
+fn = _lib.lib.hm_sp_profile
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+buf = np.zeros(32, dtype=np.uint64)
+cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=1, concurrent_games=games, max_macro_plies=40)
+sp = hm.SelfPlay(cfg, N.FusedNet(N.rise_v3_small()))
+fn(None, 1)
+res = sp.run()
+fn(buf.ctypes.data, 0)
+names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "select_child(puct)", "jb_make", "canonicalize_child",
+         "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total"]
+it = res.search_iterations
+print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
+for i, n in enumerate(names):
+    cyc, cnt = int(buf[i]), int(buf[16 + i])
+    print(f"{n:28s} cycles/iter {cyc / max(it, 1):10.0f}   calls/iter {cnt / max(it, 1):6.2f}   cycles/call {cyc / max(cnt, 1):9.0f}")

@@ -45,4 +45,6 @@ print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searche
                       term=list(res.terminations), bytes=res.record_bytes, chunk_samples=len(samples),
                       leg_ms=dict(collect=res.collect_ms / max(res.search_iterations, 1), net=res.eval_ms / max(res.search_iterations, 1),
                                   process=res.process_ms / max(res.search_iterations, 1)),
-                      iter_ms=res.seconds * 1e3 / max(res.eval_batches, 1))))
+                      iter_ms=res.seconds * 1e3 / max(res.eval_batches, 1), search_iter_ms=res.search_seconds * 1e3 / max(res.search_iterations, 1),
+                      split_s=dict(search=res.search_seconds, prologue=res.prologue_seconds, raw=res.raw_seconds,
+                                   host=res.seconds - res.search_seconds - res.prologue_seconds - res.raw_seconds))))
