@@ -237,7 +237,9 @@ constexpr u32 ILLEGAL_FLAG = 0x80000000u;
 // Ordered legal move list (generate<LEGAL>), written to out[0..n).  `out` may point to LDS
 // or global memory.  Returns n.  Pseudo-legal moves are emitted in the reference's order with
 // an illegal flag, then compacted with the reference's swap-with-last rule (movegen.cpp:449-453).
-__device__ inline int gen_legal(const AttackTab& t, const P& p, u32* out) {
+// `p` is taken by value: the generator is a real call (not inlined), and a by-reference argument would pin
+// the caller's position in scratch memory for its whole lifetime.
+__device__ __attribute__((noinline)) int gen_legal(const AttackTab& t, const P p, u32* out) {
     Analysis an;
     analyse(t, p, an);
     const int us = p.stm, them = us ^ 1, k = an.ksq;

@@ -16,6 +16,7 @@
 // provided scratch (LDS).
 #pragma once
 #include "hm_device.hpp"
+#include "hm_prof.hpp"
 
 namespace hmd {
 
@@ -120,12 +121,12 @@ __device__ inline bool has_useful_capture(const RulesTab& t, const P& q, int par
 }
 
 // board.cc:214-314.  bd[0], bd[1] = BOARD_A, BOARD_B.  scratch: 2 lists of HM_MAX_MOVES.
-__device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, const P* bd, int boardInCheck, int checkedSide, bool adv, u32* scratch) {
-    const int pb = 1 - boardInCheck;
+__device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, const P bdA, const P bdB, int boardInCheck, int checkedSide, bool adv, u32* scratch) {
+    // by-value copies: callers keep their positions in registers
+    const P p = boardInCheck ? bdB : bdA, partner = boardInCheck ? bdA : bdB;
     const int partnerSide = checkedSide ^ 1;
-    const bool partnerTurn = (int)bd[pb].stm == partnerSide;
+    const bool partnerTurn = (int)partner.stm == partnerSide;
     if (!partnerTurn && !adv) return false;
-    const P& p = bd[boardInCheck];
     const int k = lsb(p.bt[5] & bc_of(p, checkedSide));
     const u64 chk = checkers_of(t.att, p);
     if (chk & (chk - 1)) return false;
@@ -134,14 +135,14 @@ __device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, con
     const u64 avail = blocking & ~occ_of(p);
     if (!avail) return false;
     const bool pawnValid = (avail & ~(RANK_1 | RANK_8)) != 0;
-    if (partnerTurn) return has_useful_capture(t, bd[pb], partnerSide, pawnValid, scratch);
+    if (partnerTurn) return has_useful_capture(t, partner, partnerSide, pawnValid, scratch);
     // time advantage: every opponent reply must leave the partner an immediate useful capture
     u32* replies = scratch;
     u32* inner = scratch + HM_MAX_MOVES;
-    const int n = gen_legal(t.att, bd[pb], replies);
+    const int n = gen_legal(t.att, partner, replies);
     if (!n) return false;
     for (int i = 0; i < n; ++i) {
-        P f = bd[pb];
+        P f = partner;
         do_move(t.att, t.zob, f, replies[i]);          // hands of the other board are irrelevant here
         if (!has_useful_capture(t, f, partnerSide, pawnValid, inner)) return false;
     }
@@ -152,7 +153,7 @@ __device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, con
 __device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, int& cntB) {
     const int lane = threadIdx.x & 63;
     int c = 0;
-    if (lane < 2) c = count_legal(t.att, bd[lane]);
+    if (lane < 2) c = count_legal(t.att, pick_pos(bd, lane));
     cntA = __shfl(c, 0); cntB = __shfl(c, 1);
 }
 
@@ -160,10 +161,10 @@ __device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, i
 __device__ inline bool is_checkmate_c(const RulesTab& t, const P* bd, int side, bool adv, int cntA, int cntB, u32* scratch) {
     const bool onA = (int)bd[0].stm == side, onB = (int)bd[1].stm == (side ^ 1);
     if (onA) {
-        if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd, 0, side, adv, scratch)) return true;
+        if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 0, side, adv, scratch)) return true;
     }
     if (onB) {
-        if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd, 1, side ^ 1, adv, scratch)) return true;
+        if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 1, side ^ 1, adv, scratch)) return true;
     }
     if (onA || onB) {
         const bool movesA = onA && cntA > 0, movesB = onB && cntB > 0;
@@ -178,11 +179,11 @@ __device__ inline bool is_checkmate(const RulesTab& t, const P* bd, int side, bo
     int cntA = -1, cntB = -1;
     if (onA) {
         cntA = count_legal(t.att, bd[0]);
-        if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd, 0, side, adv, scratch)) return true;
+        if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 0, side, adv, scratch)) return true;
     }
     if (onB) {
         cntB = count_legal(t.att, bd[1]);
-        if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd, 1, side ^ 1, adv, scratch)) return true;
+        if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 1, side ^ 1, adv, scratch)) return true;
     }
     if (onA || onB) {
         const bool movesA = onA && cntA > 0, movesB = onB && cntB > 0;
@@ -203,12 +204,14 @@ struct JBoard {
     int hlen[2];
     u64 prefix[2];
 };
-__device__ __forceinline__ Hist hist_of(const JBoard& j, int b) { return Hist{j.hist[b], j.hlen[b], j.prefix[b]}; }
+__device__ __forceinline__ Hist hist_of(const JBoard& j, int b) {   // no runtime subscripts: JBoard stays in registers
+    return b ? Hist{j.hist[1], j.hlen[1], j.prefix[1]} : Hist{j.hist[0], j.hlen[0], j.prefix[0]};
+}
 __device__ inline bool jb_is_draw(const JBoard& j, int ply) {
     return is_draw_on_board(j.bd[0], hist_of(j, 0), ply) || is_draw_on_board(j.bd[1], hist_of(j, 1), ply);
 }
 // Board::push_move incl. history (board.cc:98-108); only `lane0` writes the history array.
-__device__ inline void jb_push(const RulesTab& t, JBoard& j, int b, u32 m, bool writer) {
+__device__ __forceinline__ void jb_push(const RulesTab& t, JBoard& j, int b, u32 m, bool writer) {
     const int h = do_move(t.att, t.zob, j.bd[b], m);
     if (h) add_to_hand(t.zob, j.bd[1 - b], h);
     const u64 k = rep_key(t, j.bd[b]);
@@ -216,7 +219,7 @@ __device__ inline void jb_push(const RulesTab& t, JBoard& j, int b, u32 m, bool 
     j.hlen[b]++;
     j.prefix[b] = mix_hash(j.prefix[b], k);
 }
-__device__ inline void jb_make(const RulesTab& t, JBoard& j, u32 ma, u32 mb, bool writer) {   // board.cc:316-341
+__device__ __forceinline__ void jb_make(const RulesTab& t, JBoard& j, u32 ma, u32 mb, bool writer) {   // board.cc:316-341
     if (ma) jb_push(t, j, 0, ma, writer);
     if (mb) jb_push(t, j, 1, mb, writer);
 }
@@ -228,7 +231,8 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
     const int lane = threadIdx.x & 63;
     u32* list = scratch;
     int n = 0;
-    if (lane == 0) n = gen_legal(t.att, j.bd[b], list);
+    const P src = pick_pos(j.bd, b), other = pick_pos(j.bd, 1 - b);
+    if (lane == 0) n = gen_legal(t.att, src, list);
     n = __shfl(n, 0);
     __builtin_amdgcn_wave_barrier();
     int k = 0;
@@ -236,12 +240,14 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
         const int i = base + lane;
         bool cand = false;
         if (i < n) {
-            P nb[2] = {j.bd[0], j.bd[1]};
-            const int h = do_move(t.att, t.zob, nb[b], list[i]);
-            if (checkers_of(t.att, nb[b])) {
-                if (h) add_to_hand(t.zob, nb[1 - b], h);
-                const bool vA = (int)nb[0].stm == victimTeam, vB = (int)nb[1].stm == (victimTeam ^ 1);
-                cand = (vA && count_legal(t.att, nb[0]) == 0) || (vB && count_legal(t.att, nb[1]) == 0);
+            P moved = src, partner = other;
+            const int h = do_move(t.att, t.zob, moved, list[i]);
+            if (checkers_of(t.att, moved)) {
+                if (h) add_to_hand(t.zob, partner, h);
+                // victim's on-turn boards: board A plays victimTeam's colour, board B the opposite colour
+                const bool vMoved = (int)moved.stm == (b ? victimTeam ^ 1 : victimTeam);
+                const bool vPartner = (int)partner.stm == (b ? victimTeam : victimTeam ^ 1);
+                cand = (vMoved && count_legal(t.att, moved) == 0) || (vPartner && count_legal(t.att, partner) == 0);
             }
         }
         u64 mask = __ballot(cand);
@@ -249,9 +255,11 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
             const int q = __builtin_ctzll(mask);
             mask &= mask - 1;
             const u32 m = list[base + q];
-            P nb[2] = {j.bd[0], j.bd[1]};
-            const int h = do_move(t.att, t.zob, nb[b], m);
-            if (h) add_to_hand(t.zob, nb[1 - b], h);
+            P moved = src, partner = other;
+            const int h = do_move(t.att, t.zob, moved, m);
+            if (h) add_to_hand(t.zob, partner, h);
+            P nb[2];
+            put_pos(nb, b, moved); put_pos(nb, 1 - b, partner);
             if (is_checkmate(t, nb, victimTeam, victimAdv, scratch + HM_MAX_MOVES)) out[k++] = m;
         }
     }
@@ -268,42 +276,47 @@ __device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, con
     const int nm = immediate_mates_on_board(t, j, waiting, team, adv, mating, scratch + HM_MAX_MOVES);
     if (!nm) return false;
     u32* replies = scratch + HM_MAX_MOVES;
-    int nr = gen_legal(t.att, j.bd[active], replies);
+    const P actP = pick_pos(j.bd, active), waitP = pick_pos(j.bd, waiting);
+    int nr = gen_legal(t.att, actP, replies);
     if (adv) replies[nr++] = 0;
     if (!nr) return false;
     u32* tmp = scratch + 2 * HM_MAX_MOVES;                    // 4 lists left
     for (int r = 0; r < nr; ++r) {
         const u32 reply = replies[r];
-        P nb[2] = {j.bd[0], j.bd[1]};
+        P na = actP, nw = waitP;                       // boards after the reply: active / waiting
         bool drawAfter;
         if (reply) {
-            const int h = do_move(t.att, t.zob, nb[active], reply);
-            if (h) add_to_hand(t.zob, nb[1 - active], h);
+            const int h = do_move(t.att, t.zob, na, reply);
+            if (h) add_to_hand(t.zob, nw, h);
             // is_draw(searchPly+1) on the pushed position: active board's history gains one key
-            const u64 k = rep_key(t, nb[active]);
-            bool d = nb[active].rule50 >= 100;
+            const u64 k = rep_key(t, na);
+            bool d = na.rule50 >= 100;
             if (!d) {   // threshold 1 (ply > 0): any earlier occurrence
                 const Hist h0 = hist_of(j, active);
                 bool f = false;
                 for (int i = threadIdx.x & 63; i < h0.len; i += 64) f |= h0.keys[i] == k;
                 d = __ballot(f) != 0ULL;
             }
-            drawAfter = d || is_draw_on_board(nb[waiting], hist_of(j, waiting), searchPly + 1);
+            drawAfter = d || is_draw_on_board(nw, hist_of(j, waiting), searchPly + 1);
         } else {
             drawAfter = jb_is_draw(j, searchPly + 1);
         }
         bool persists = false;
+        P nb[2];
+        put_pos(nb, active, na); put_pos(nb, waiting, nw);
         if (!is_checkmate(t, nb, team ^ 1, !adv, tmp) && !drawAfter) {
             for (int i = 0; i < nm && !persists; ++i) {
                 const u32 mm = mating[i];
                 // is_legal_move(waiting, mm)
-                const int nl = gen_legal(t.att, nb[waiting], tmp);
+                const int nl = gen_legal(t.att, nw, tmp);
                 bool legal = false;
                 for (int q = 0; q < nl; ++q) legal |= tmp[q] == mm;
                 if (!legal) continue;
-                P nb2[2] = {nb[0], nb[1]};
-                const int h = do_move(t.att, t.zob, nb2[waiting], mm);
-                if (h) add_to_hand(t.zob, nb2[1 - waiting], h);
+                P ma = na, mw = nw;
+                const int h = do_move(t.att, t.zob, mw, mm);
+                if (h) add_to_hand(t.zob, ma, h);
+                P nb2[2];
+                put_pos(nb2, active, ma); put_pos(nb2, waiting, mw);
                 persists = is_checkmate(t, nb2, team, adv, tmp);
             }
         }
@@ -313,15 +326,25 @@ __device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, con
 }
 
 // searchthread.cc:101-139.  Returns 0 NONE, 1 WIN, 2 LOSS, 3 DRAW (== NodeType numbering).
-__device__ inline int classify_terminal_position(const RulesTab& t, const JBoard& j, int teamToPlay, int rootTeam, bool rootAdv, int searchPly, int* endInPly, u32* scratch) {
+__device__ __forceinline__ int classify_terminal_position(const RulesTab& t, const JBoard& j, int teamToPlay, int rootTeam, bool rootAdv, int searchPly, int* endInPly, u32* scratch) {
     *endInPly = 0;
     const bool adv = teamToPlay == rootTeam ? rootAdv : !rootAdv;
     int cntA, cntB;
+    PROF_T(t0);
     legal_counts(t, j.bd, cntA, cntB);               // each board's count serves exactly one of the two tests
+    PROF_ADD(15, t0);
+    PROF_T(t1);
     if (is_checkmate_c(t, j.bd, teamToPlay ^ 1, !adv, cntA, cntB, scratch)) { *endInPly = 1; return 1; }
     if (is_checkmate_c(t, j.bd, teamToPlay, adv, cntA, cntB, scratch)) { *endInPly = 1; return 2; }
-    if (jb_is_draw(j, searchPly)) return 3;
-    if (searchPly > 0 && has_unavoidable_waiting_board_mate(t, j, teamToPlay, adv, searchPly, scratch)) { *endInPly = 3; return 2; }
+    PROF_ADD(16, t1);
+    PROF_T(t2);
+    const bool drawn = jb_is_draw(j, searchPly);
+    PROF_ADD(17, t2);
+    if (drawn) return 3;
+    PROF_T(t3);
+    const bool wmate = searchPly > 0 && has_unavoidable_waiting_board_mate(t, j, teamToPlay, adv, searchPly, scratch);
+    PROF_ADD(18, t3);
+    if (wmate) { *endInPly = 3; return 2; }
     return 0;
 }
 

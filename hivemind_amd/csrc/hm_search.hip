@@ -35,6 +35,7 @@
 #include <string>
 #include <vector>
 
+#include "hm_prof.hpp"
 #include "hm_rules_device.hpp"
 #include "hm_host.hpp"
 
@@ -139,15 +140,7 @@ struct Pools {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
-// Diagnostic cycle accounting of game slot 0 (build with -DHM_SEARCH_PROF; read with hm_sp_profile).
-__device__ unsigned long long g_prof[32];
-#ifdef HM_SEARCH_PROF
-#define PROF_T(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
-#define PROF_ADD(slot, t) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_prof[slot] += __builtin_amdgcn_s_memtime() - (t); g_prof[16 + (slot)]++; } } while (0)
-#else
-#define PROF_T(t) do {} while (0)
-#define PROF_ADD(slot, t) do {} while (0)
-#endif
+__device__ unsigned long long g_prof[64];      // hm_prof.hpp probes (all zero in the product build)
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -451,6 +444,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
     const float explorationBase = c * sqrtVisits;
     float visitedPolicySum = 0.0f;
     bool hasNonLosing = false;
+    PROF_T(tq1);
     // edges are loaded lane-parallel; the prior sum is then accumulated in index order (the
     // reference adds childPriors in a plain loop) from registers via shuffles
     for (int base = 0; base < limit; base += 64) {
@@ -477,6 +471,8 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
         ? clampf(parentQ - s.prm->fpuReduction * sqrtf(fmaxf(0.0f, visitedPolicySum)), -1.0f, 1.0f) : Q_INIT;
     for (int w = 0; w < 8; ++w) unavailMask[w] = 0;
     int pending = -1;
+    PROF_ADD(19, tq1);
+    PROF_T(tq2);
     while (true) {
         float bestScore = -INFINITY;
         int bestIdx = -1;
@@ -524,6 +520,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
         }
         e[bestIdx].vloss++;
         s.nodes[nodeId].vvsum = n.vvsum + 1;
+        PROF_ADD(20, tq2);
         return {child, bestIdx, reserved, -1};
     }
 }
@@ -573,7 +570,7 @@ __device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, Traj
 }
 
 // searchthread.cc:818-916.  Returns leaf node id or -1; traj/p updated.
-__device__ inline int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, bool rootAdv, int rootTeam, bool* reservedOut, u64* unavailMask) {
+__device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, bool rootAdv, int rootTeam, bool* reservedOut, u64* unavailMask) {
     int cur = s.g->root;
     bool reserved = false;
     traj[0] = TrajEnt{cur, -1, 0, 0};
@@ -760,12 +757,13 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     const bool leafAdv = team == rootTeam ? rootAdv : !rootAdv;
     const bool aOn = (int)bd[0].stm == team, bOn = (int)bd[1].stm == (team ^ 1);
     // legal moves of the on-turn boards: lane 0 -> A, lane 1 -> B (same code path, no divergence)
+    PROF_T(te1);
     int cntMine = 0;
     if (lane < 2) {
         const bool on = lane == 0 ? aOn : bOn;
         if (on) {
             u32* list = L.lists[lane];
-            int n = gen_legal(rt.att, bd[lane], list);
+            int n = gen_legal(rt.att, pick_pos(bd, lane), list);
             int k = 0;
             for (int i = 0; i < n; ++i) {                      // erase R/B under-promotions (utils.h:169-182), order kept
                 const u32 m = list[i];
@@ -778,6 +776,8 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     int nReal[2];
     nReal[0] = __shfl(cntMine, 0); nReal[1] = __shfl(cntMine, 1);
     __builtin_amdgcn_wave_barrier();
+    PROF_ADD(21, te1);
+    PROF_T(te2);
     int nAct[2];
     for (int b = 0; b < 2; ++b) {
         u32* list = L.lists[b];
@@ -789,7 +789,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         if (n == 0) { pr[0] = 1.0f; __builtin_amdgcn_wave_barrier(); continue; }
         // get_normalized_probability (utils.h:226-243): gather fp16 logits through the policy tables
         const uint16_t* pol = b == 0 ? piA : piB;
-        const int stm = (int)bd[b].stm;
+        const int stm = (int)(b ? bd[1].stm : bd[0].stm);
         float mx = -INFINITY;
         for (int i = lane; i < n + 1; i += 64) {
             const u32 m = list[i];
@@ -820,6 +820,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         for (int i = lane; i < n + 1; i += 64) pr[i] = (float)((double)pr[i] / sum);
         __builtin_amdgcn_wave_barrier();
     }
+    PROF_ADD(22, te2);
     // root Dirichlet noise (node.h:286-315): gamma draws were made on the host
     Node leaf = s.nodes[ctx.leaf];
     if (leaf.depth == 0 && s.g->alpha > 0.0f && s.g->eps > 0.0f) {
@@ -852,6 +853,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     h.heapCap = 16; h.heapSize = 0; h.heap = arena_alloc(s, h.heapCap * 8);
     h.visCap = 32; h.visSize = 0; h.visited = arena_alloc(s, h.visCap * 4);
     if (!offM[0] || !offP[0] || !offM[1] || !offP[1] || !h.heap || !h.visited) return;
+    PROF_T(te3);
     for (int b = 0; b < 2; ++b) {
         const int n = nAct[b];
         const u32* list = L.lists[b];
@@ -863,12 +865,14 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
             int rank = 0;
             for (int j = 0; j < n; ++j) { const float pj = pr[j]; rank += (pj > pi) || (pj == pi && j < i); }
             const u32 m = list[i];
-            const u32 cap = (m != 0 && is_capture(bd[b], m)) ? 0x80000000u : 0u;
+            const u32 cap = (m != 0 && (b ? is_capture(bd[1], m) : is_capture(bd[0], m))) ? 0x80000000u : 0u;
             outM[rank] = m | cap;
             outP[rank] = pi;
         }
     }
     wave_fence();
+    PROF_ADD(23, te3);
+    PROF_T(te4);
     h.movesA = offM[0]; h.movesB = offM[1]; h.priorsA = offP[0]; h.priorsB = offP[1];
     gen_push(s, h, 0, 0);
     if (h.heapSize == 0) { gen_push(s, h, 1, 0); gen_push(s, h, 0, 1); }
@@ -889,6 +893,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     }
     *reinterpret_cast<GenHdr*>(s.arena + genOff) = h;
     s.nodes[ctx.leaf] = leaf;
+    PROF_ADD(24, te4);
 }
 
 __device__ inline float shape_value(const G& s, uint16_t valueH, const uint16_t* wdl, uint16_t mlH) {   // searchthread.cc:569-619
@@ -980,7 +985,7 @@ __device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
 }
 
 // collect_batch (searchthread.cc:255-442).  Planes of NN leaves go to planesOut + slot*4736 (fp16).
-__device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, uint16_t* planesOut) {
+__device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, uint16_t* planesOut) {
     const int lane = threadIdx.x & 63;
     int nctx = 0, valid = 0, attempts = 0;
     Path p;
@@ -988,6 +993,7 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
         attempts++;
         PROF_T(t0);
         path_reset(s, p);
+        PROF_ADD(13, t0);
         bool reserved = false;
         const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
         PROF_ADD(0, t0);
@@ -1052,7 +1058,10 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
                     hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
                 }
                 wave_fence();
+                PROF_ADD(25, tp);
+                PROF_T(tw);
                 write_planes_f16(rt, L.board, reinterpret_cast<uint4*>(planesOut + (size_t)valid * HM_PLANE_VALUES), L.pmask, L.pval);
+                PROF_ADD(26, tw);
                 PROF_ADD(7, tp);
                 valid++;
             }
@@ -1081,25 +1090,25 @@ __device__ inline void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int b
 // searchthread.cc:680-688).  A game with no batch in flight collects its first batch into NEXT and
 // marks it `fresh`; its lookahead follows one iteration later (same order of tree operations as
 // run_iteration: collect b0, collect b1, process b0).  Runs on one wave.
-__device__ inline int collect_step(G& s, const RulesTab& rt, WaveLds& L, uint16_t* planesNext, int g) {   // returns the plane rows written
+__device__ __forceinline__ int collect_step(G& s, const RulesTab& rt, WaveLds& L, uint16_t* planesNext, int g) {   // returns the plane rows written
     if (s.g->status != ST_SEARCHING) return 0;
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
     uint16_t* nxt = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
-    // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
-    while (s.g->pending < 0) {
+    // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678).  One collect_batch call
+    // site: with nothing in flight the first batch goes to buffer 0, otherwise the lookahead to the other one.
+    for (;;) {
         if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return 0; }
-        collect_batch(s, rt, L, 0, rootTeam, rootAdv, nxt);
+        const bool first = s.g->pending < 0;
+        const int buf = first ? 0 : 1 - s.g->pending;
+        collect_batch(s, rt, L, buf, rootTeam, rootAdv, nxt);
+        if (!first) return s.g->validCount[buf];
         if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return 0; }   // no progress possible
         if (s.g->validCount[0] == 0) { process_batch(s, rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
         s.g->pending = 0;
         s.g->fresh = 1;
         return s.g->validCount[0];
     }
-    if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return 0; }
-    const int look = 1 - s.g->pending;
-    collect_batch(s, rt, L, look, rootTeam, rootAdv, nxt);
-    return s.g->validCount[look];
 }
 
 // One lockstep iteration, process side, for a block of BATCH waves.  Returns on every wave; only
@@ -1141,7 +1150,9 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
         } else {
             const int look = 1 - pending;
             s.g->pending = -1;
+            PROF_T(tb);
             backup_batch(s, pending, &out, rowBase);
+            PROF_ADD(14, tb);
             if (s.g->validCount[look] == 0) process_batch(s, rt, exp[0], look, rootTeam, rootAdv, nullptr, 0);
             else s.g->pending = look;
             if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
@@ -1156,6 +1167,7 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
+    PROF_INIT();
     PROF_T(ta);
     stage_table(&s_rt, pl.rules);
     __syncthreads();
@@ -1164,15 +1176,18 @@ __global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* 
     const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
     if (rowsNext && threadIdx.x == 0) rowsNext[blockIdx.x] = rows;     // batch size of this game for the evaluator
     PROF_ADD(10, ta);
+    PROF_FLUSH();
 }
 
 __global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
     __shared__ RulesTab s_rt;
     __shared__ ExpLds s_exp[BATCH];
+    PROF_INIT();
     stage_table(&s_rt, pl.rules);
     __syncthreads();
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
+    PROF_FLUSH();
 }
 
 // Fused tree step of the pipelined driver: process(batch i-1) then collect(batch i+1) in ONE launch
@@ -1813,10 +1828,10 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
 
-// diagnostic (all zeros unless built with -DHM_SEARCH_PROF): out[0..15] cycles, out[16..31] counts; reset != 0 clears
-int hm_sp_profile(unsigned long long* out32, int reset) {
-    if (out32) HIPCHK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32));
-    if (reset) { unsigned long long z[32] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
+// diagnostic (all zeros unless built with -DHM_SEARCH_PROF): out[0..31] cycles, out[32..63] counts; reset != 0 clears
+int hm_sp_profile(unsigned long long* out64, int reset) {
+    if (out64) HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));
+    if (reset) { unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
     return HM_OK;
 }
 // fused process(previous heads) + collect(next planes); counts active games into d_active2[parity]

@@ -24,16 +24,18 @@ hm.init(0)
 torch.manual_seed(0)
 fn = _lib.lib.hm_sp_profile
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
-buf = np.zeros(32, dtype=np.uint64)
+buf = np.zeros(64, dtype=np.uint64)
 cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=1, concurrent_games=games, max_macro_plies=40)
 sp = hm.SelfPlay(cfg, N.FusedNet(N.rise_v3_small()))
 fn(None, 1)
 res = sp.run()
 fn(buf.ctypes.data, 0)
 names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "select_child(puct)", "jb_make", "canonicalize_child",
-         "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total"]
+         "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total", "path_reset", "process: backup_batch",
+         "classify: legal_counts", "classify: checkmate x2", "classify: draw", "classify: waiting-board mate", "puct: pass 1", "puct: arg-max loop",
+         "expand: movegen", "expand: softmax", "expand: rank sort", "expand: generator init", "planes: hash+store", "planes: write"]
 it = res.search_iterations
 print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
 for i, n in enumerate(names):
-    cyc, cnt = int(buf[i]), int(buf[16 + i])
+    cyc, cnt = int(buf[i]), int(buf[32 + i])
     print(f"{n:28s} cycles/iter {cyc / max(it, 1):10.0f}   calls/iter {cnt / max(it, 1):6.2f}   cycles/call {cyc / max(cnt, 1):9.0f}")
