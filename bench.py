@@ -194,19 +194,23 @@ def main():
         legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
                 "k_process (expand+backup)": tot["process_ms"] / it}
         dominant = max(legs, key=legs.get)
-        if dominant.startswith("RISEv3"):
-            rows = args.games * 8
-            ach = rows * flops / (legs[dominant] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                    "traffic": None, "kernel": dominant, "kernel_ms": legs[dominant],
-                    "algorithmic_flops_per_launch": rows * flops}
-        else:
-            # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node
-            by = (tot["nv"] * (64 + 104) + tot["es"] * 40) / it
-            ach = by / (legs[dominant] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": dominant, "kernel_ms": legs[dominant], "algorithmic_bytes_per_launch": by,
-                    "note": "latency-bound pointer chase: one wavefront per game; see DESIGN.md"}
+        # the forward evaluates only the rows that hold a leaf (ragged batch, hm_net_forward_groups)
+        rows = tot["eval_rows"] / it
+        net_ms = legs["RISEv3 forward (net)"]
+        ach = rows * flops / (net_ms * 1e-3) / 1e12
+        roof_net = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                    "traffic": None, "kernel": "RISEv3 forward (net)", "kernel_ms": net_ms,
+                    "algorithmic_flops_per_launch": rows * flops, "rows_per_launch": rows}
+        # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node,
+        # plus the 9472-byte fp16 plane tensor of every leaf
+        tree_ms = legs["k_collect (tree traversal)"]
+        by = (tot["nv"] * (64 + 104) + tot["es"] * 40) / it + rows * 9472
+        ach = by / (tree_ms * 1e-3) / 1e9
+        roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_collect (tree traversal)", "kernel_ms": tree_ms, "algorithmic_bytes_per_launch": by,
+                     "note": "latency-bound: one wavefront per game walks its tree with dependent loads; see DESIGN.md"}
+        roof = roof_net if dominant.startswith("RISEv3") else roof_tree
+        extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
                              "lockstep_iterations": tot["iters"], "leg_ms_per_iteration": legs,
                              "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9}
@@ -228,9 +232,12 @@ def main():
             extra["selfplay_256_concurrent_games"] = {"positions_per_s": r.samples / r.seconds, "nodes_per_s": r.total_nodes / r.seconds,
                                                       "leg_ms_per_iteration": {"collect": r.collect_ms / it256, "net": r.eval_ms / it256,
                                                                                "process": r.process_ms / it256},
-                                                      "net_TFLOPs": 2048 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
+                                                      "net_TFLOPs": r.eval_rows / it256 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
             pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
             extra["plane_encode_64k"] = pl
+            extra["rooflines"].append({"bound": "hbm", "achieved": pl["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": pl["hbm_frac"], "traffic": None, "kernel": "encode_planes_kernel<f16>",
+                                       "kernel_ms": pl["kernel_ms"], "algorithmic_bytes_per_launch": pl["algorithmic_bytes_per_launch"]})
             if rank == 0 and not args.no_cpu_baseline:
                 extra["plane_encode_64k"]["cpu_baseline"] = cpu_planes_baseline(boards, out, 5.0)
         if not args.no_extra and args.perft_depth > 0:

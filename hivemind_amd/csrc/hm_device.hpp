@@ -149,6 +149,12 @@ __device__ __forceinline__ void load_pos(P& p, const hm_pos* g) {
     p.rule50 = (u32)(b >> 40) & 0xff;
     p.ply = (u32)(b >> 48) & 0xffff;
 }
+// Results of wave reductions / lane-0 work are equal in every lane but the compiler cannot know it; these
+// hand them back as scalar values so that the control flow and arithmetic that follow stay on the scalar unit.
+__device__ __forceinline__ int ufirst(int v) { return (int)__builtin_amdgcn_readfirstlane((u32)v); }
+__device__ __forceinline__ float ufirstf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ int ulane(int v, int lane) { return (int)__builtin_amdgcn_readlane((u32)v, lane); }
+__device__ __forceinline__ float ulanef(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 __device__ __forceinline__ void store_pos(hm_pos* g, const P& p) {
     u64* w = reinterpret_cast<u64*>(g);
 #pragma unroll

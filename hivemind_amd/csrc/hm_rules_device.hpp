@@ -75,7 +75,7 @@ __device__ inline int repetition_count(const Hist& h) {
     int c = 0;
     for (int i = threadIdx.x & 63; i < h.len; i += 64) c += h.keys[i] == cur;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    return c;
+    return ufirst(c);
 }
 __device__ inline bool is_draw_on_board(const P& p, const Hist& h, int ply) {   // board.h:423-453
     if (p.rule50 >= 100) return true;
@@ -84,7 +84,7 @@ __device__ inline bool is_draw_on_board(const P& p, const Hist& h, int ply) {   
     int c = 0;
     for (int i = threadIdx.x & 63; i + 1 < h.len; i += 64) c += h.keys[i] == cur;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    return c >= threshold;
+    return ufirst(c) >= threshold;
 }
 
 __device__ __forceinline__ u64 checkers_of(const AttackTab& t, const P& p) {
@@ -154,7 +154,7 @@ __device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, i
     const int lane = threadIdx.x & 63;
     int c = 0;
     if (lane < 2) c = count_legal(t.att, pick_pos(bd, lane));
-    cntA = __shfl(c, 0); cntB = __shfl(c, 1);
+    cntA = ulane(c, 0); cntB = ulane(c, 1);
 }
 
 // board.cc:169-208 with the per-board MoveList<LEGAL>::size() values supplied.  scratch: 2 lists.
@@ -233,7 +233,7 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
     int n = 0;
     const P src = pick_pos(j.bd, b), other = pick_pos(j.bd, 1 - b);
     if (lane == 0) n = gen_legal(t.att, src, list);
-    n = __shfl(n, 0);
+    n = ulane(n, 0);
     __builtin_amdgcn_wave_barrier();
     int k = 0;
     for (int base = 0; base < n; base += 64) {

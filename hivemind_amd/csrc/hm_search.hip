@@ -182,7 +182,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ULL; }
 __device__ __forceinline__ bool wave_all(bool p) { return __ballot(!p) == 0ULL; }
 __device__ __forceinline__ int wave_sum_i(int v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    return ufirst(v);
 }
 
 struct G {               // per-wave view of one game's pools
@@ -207,14 +207,14 @@ __device__ inline u32 arena_alloc(G& s, u32 bytes) {
     const u32 units = (bytes + 7) >> 3;
     u32 top = 0;
     if ((threadIdx.x & 63) == 0) top = atomicAdd(&s.g->arenaTop, units);
-    top = __shfl(top, 0);
+    top = (u32)ulane((int)top, 0);
     if (top + units > s.prm->arenaCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 1); return 0; }
     return top;
 }
 __device__ inline int node_alloc(G& s, int team, int depth) {
     int id = 0;
     if ((threadIdx.x & 63) == 0) id = atomicAdd(&s.g->nodeCount, 1);
-    id = __shfl(id, 0);
+    id = ulane(id, 0);
     if (id >= s.prm->nodeCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 2); return -1; }
     Node n;
     n.hash = 0; n.valueSum = 0.0f; n.visits = 0; n.vvsum = 0; n.expanded = 0; n.endInPly = 0; n.unsolved = 0; n.cntTypes = 0;
@@ -460,10 +460,8 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
         hasNonLosing |= wave_any(nonLosing);
         const u64 cmask = __ballot(counted);
         const int cnt = limit - base < 64 ? limit - base : 64;
-        for (int k = 0; k < cnt; ++k) {
-            const float pk = __shfl(pr, k);
-            if ((cmask >> k) & 1) visitedPolicySum += pk;
-        }
+        (void)cnt;
+        for (u64 m = cmask; m; m &= m - 1) visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
     }
     hasNonLosing &= n.type == T_UNSOLVED;
     const float parentQ = visits > 0 ? (n.valueSum / (float)visits) : 0.0f;
@@ -503,6 +501,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
                 const int oid = __shfl_xor(id, off);
                 if (osc > sc || (osc == sc && oid < id)) { sc = osc; id = oid; }
             }
+            sc = ufirstf(sc); id = ufirst(id);
             if (id != 0x7fffffff && sc > bestScore) { bestScore = sc; bestIdx = id; }
         }
         if (bestIdx < 0) return {-1, -1, false, pending};
@@ -774,7 +773,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         }
     }
     int nReal[2];
-    nReal[0] = __shfl(cntMine, 0); nReal[1] = __shfl(cntMine, 1);
+    nReal[0] = ulane(cntMine, 0); nReal[1] = ulane(cntMine, 1);
     __builtin_amdgcn_wave_barrier();
     PROF_ADD(21, te1);
     PROF_T(te2);
@@ -806,6 +805,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
             if (finite_f(lg)) mx = fmaxf(mx, lg);
         }
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        mx = ufirstf(mx);
         __builtin_amdgcn_wave_barrier();
         if (!finite_f(mx)) {                                   // normalize_logits fallback :136-141
             for (int i = lane; i < n + 1; i += 64) pr[i] = 1.0f / (float)(n + 1);
@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         int nA = 0, nB = 0;
         if (lane == 0 && aOn) nA = gen_legal(rt.att, p.jb.bd[0], la);
         if (lane == 1 && bOn) nB = gen_legal(rt.att, p.jb.bd[1], lb);
-        nA = __shfl(nA, 0); nB = __shfl(nB, 1);
+        nA = ulane(nA, 0); nB = ulane(nB, 1);
         rootHashOut[2 * g + 1] = (u64)(u32)(nA + 1) | ((u64)(u32)(nB + 1) << 32);
         __builtin_amdgcn_wave_barrier();
         const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;
