@@ -14,3 +14,14 @@ __shared__ unsigned long long s_prof[64];
 #define PROF_INIT() do {} while (0)
 #define PROF_FLUSH() do {} while (0)
 #endif
+
+// Event log of collect_batch for one game slot (build with -DHM_SEARCH_TRACE; read with hm_sp_trace).  Same encoding
+// as the oracle's Search::ctxTrace: (collect# << 32) | (code << 24) | (path length << 8) | outcome.
+#ifdef HM_SEARCH_TRACE
+#define TRACE_EV(code, len, outcome) do { if ((int)blockIdx.x == g_traceGame && (threadIdx.x & 63) == 0 && threadIdx.x < 64) { \
+    const unsigned int k_ = g_traceCount++; if (k_ < 65536u) g_trace[k_] = ((unsigned long long)g_traceSeq << 32) | ((unsigned long long)(code) << 24) | ((unsigned long long)((len) & 0xffff) << 8) | (unsigned long long)((outcome) & 0xff); } } while (0)
+#define TRACE_SEQ() do { if ((int)blockIdx.x == g_traceGame && threadIdx.x == 0) g_traceSeq++; } while (0)
+#else
+#define TRACE_EV(code, len, outcome) do {} while (0)
+#define TRACE_SEQ() do {} while (0)
+#endif

@@ -235,6 +235,7 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
     if (lane == 0) n = gen_legal(t.att, src, list);
     n = ulane(n, 0);
     __builtin_amdgcn_wave_barrier();
+    TRACE_EV(13, n, b);
     int k = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
@@ -251,6 +252,7 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
             }
         }
         u64 mask = __ballot(cand);
+        TRACE_EV(14, __popcll(mask), base);
         while (mask) {
             const int q = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -268,17 +270,20 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
 
 // searchthread.cc:41-97.  scratch: 6 lists.  `j` is used read-only; the repetition check after a
 // reply needs the history with that reply's key appended, handled on the fly.
-__device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, const JBoard& j, int team, bool adv, int searchPly, u32* scratch) {
-    const bool aOn = (int)j.bd[0].stm == team, bOn = (int)j.bd[1].stm == (team ^ 1);
-    if (aOn == bOn) return false;
+// A real call with the joint position passed by value: the rule is heavy (lane-parallel mate scan, nested
+// checkmate tests) and inlining it into the traversal kernel drives that kernel to the 512-VGPR limit.
+__device__ __attribute__((noinline)) bool waiting_board_mate_scan(const RulesTab& t, const JBoard j, int team, bool adv, int searchPly, u32* scratch) {
+    const bool aOn = (int)j.bd[0].stm == team;
     const int active = aOn ? 0 : 1, waiting = 1 - active;
     u32* mating = scratch;
     const int nm = immediate_mates_on_board(t, j, waiting, team, adv, mating, scratch + HM_MAX_MOVES);
+    TRACE_EV(10, nm, waiting);
     if (!nm) return false;
     u32* replies = scratch + HM_MAX_MOVES;
     const P actP = pick_pos(j.bd, active), waitP = pick_pos(j.bd, waiting);
     int nr = gen_legal(t.att, actP, replies);
     if (adv) replies[nr++] = 0;
+    TRACE_EV(11, nr, adv);
     if (!nr) return false;
     u32* tmp = scratch + 2 * HM_MAX_MOVES;                    // 4 lists left
     for (int r = 0; r < nr; ++r) {
@@ -320,9 +325,22 @@ __device__ inline bool has_unavoidable_waiting_board_mate(const RulesTab& t, con
                 persists = is_checkmate(t, nb2, team, adv, tmp);
             }
         }
+        TRACE_EV(12, r, (persists ? 1 : 0) | (drawAfter ? 2 : 0));
+#ifdef HM_DBG_WBM
+        if (!persists && (int)blockIdx.x == g_traceGame && threadIdx.x == 0) {
+            const unsigned k_ = g_traceCount++;
+            if (k_ < 4096u) g_trace[k_] = ((unsigned long long)r << 48) | ((unsigned long long)nr << 40) | ((unsigned long long)nm << 32) | (unsigned long long)reply | (drawAfter ? 1ULL << 31 : 0ULL);
+        }
+#endif
         if (!persists) return false;
     }
     return true;
+}
+
+__device__ __forceinline__ bool has_unavoidable_waiting_board_mate(const RulesTab& t, const JBoard& j, int team, bool adv, int searchPly, u32* scratch) {
+    const bool aOn = (int)j.bd[0].stm == team, bOn = (int)j.bd[1].stm == (team ^ 1);
+    if (aOn == bOn) return false;                     // the rule needs exactly one board on turn
+    return waiting_board_mate_scan(t, j, team, adv, searchPly, scratch);
 }
 
 // searchthread.cc:101-139.  Returns 0 NONE, 1 WIN, 2 LOSS, 3 DRAW (== NodeType numbering).

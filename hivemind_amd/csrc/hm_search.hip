@@ -35,6 +35,9 @@
 #include <string>
 #include <vector>
 
+__device__ unsigned long long g_trace[65536];   // hm_prof.hpp TRACE_EV log (diagnostic builds only)
+__device__ unsigned int g_traceCount, g_traceSeq;
+__device__ int g_traceGame = -1;
 #include "hm_prof.hpp"
 #include "hm_rules_device.hpp"
 #include "hm_host.hpp"
@@ -389,10 +392,41 @@ __device__ inline void update_child_node_type(G& s, Node& n, int idx, uint8_t ct
     }
 }
 
+// Backup of an UNSOLVED leaf: no solver bookkeeping can trigger on the way up, so every path level is an
+// independent read-modify-write and lane i updates level i; the value alternates sign from the leaf (level
+// len-1) upwards.  Returns false (nothing done) when the path must be walked sequentially.
+__device__ inline bool backup_levels(G& s, const TrajEnt* tr, int len, float v) {
+    if (len > 64) return false;
+    const int lane = threadIdx.x & 63;
+    // A transposition edge made on another path can close a cycle, so a node may occur twice on this
+    // path after all; those (rare) paths take the sequential form.
+    const int mine = lane < len ? tr[lane].node : -1 - lane;
+    bool dup = false;
+    for (int j = 0; j < len; ++j) dup |= j != lane && ulane(mine, j) == mine;
+    if (wave_any(dup)) return false;
+    for (int i = lane; i < len; i += 64) {
+        const TrajEnt t = tr[i];
+        const float vi = ((len - 1 - i) & 1) ? -v : v;
+        Node* np = &s.nodes[t.node];
+        if (t.childIdx >= 0) {
+            Edge* e = edges_of(s, *np) + t.childIdx;             // update_and_remove_virtual_loss node.h:104-121
+            const int visits = e->visits + 1;
+            e->vloss -= 1; e->visits = visits;
+            if (visits == 1) { e->vsum = vi; e->q = vi; }
+            else { const float vs = e->vsum + vi; e->vsum = vs; e->q = vs / (float)visits; }
+            np->vvsum -= 1;
+        }
+        np->valueSum += vi; np->visits += 1;
+    }
+    wave_fence();
+    return true;
+}
+
 // searchthread.cc:197-239
-__device__ inline void backup(G& s, const TrajEnt* tr, int len, float v) {
+__device__ inline void backup(G& s, const TrajEnt* tr, int len, float v, int leafType = -1) {
     if (len <= 0) return;
-    uint8_t childType = s.nodes[tr[len - 1].node].type;
+    uint8_t childType = leafType >= 0 ? (uint8_t)leafType : s.nodes[tr[len - 1].node].type;
+    if (childType == T_UNSOLVED && backup_levels(s, tr, len, v)) return;
     if (childType == T_WIN) v = 1.0f;
     else if (childType == T_LOSS) v = -1.0f;
     else if (childType == T_DRAW) v = s.nodes[tr[len - 1].node].team == s.nodes[tr[0].node].team ? -s.prm->drawContempt : s.prm->drawContempt;
@@ -926,9 +960,9 @@ __device__ inline float shape_value(const G& s, uint16_t valueH, const uint16_t*
 // independent (distinct, reserved leaves) and run one per wave; value shaping + backup then run
 // sequentially in context order on wave 0 (float sums and solver propagation are order dependent).
 __device__ inline int ctx_row(const G& s, int buf, int i) {   // inference row of context i (non-terminal contexts in order)
-    int inf = 0;
-    for (int k = 0; k < i; ++k) inf += s.ctx[buf * BATCH + k].terminal ? 0 : 1;
-    return inf;
+    const int lane = threadIdx.x & 63;
+    const bool nn = lane < i && !s.ctx[buf * BATCH + lane].terminal;      // i <= BATCH: one context per lane
+    return __popcll(__ballot(nn));
 }
 __device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
     const Ctx& ctx = s.ctx[buf * BATCH + i];
@@ -941,23 +975,29 @@ __device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int b
 }
 __device__ inline void backup_batch(G& s, int buf, const NetOut* out, int rowBase) {
     const int n = s.g->ctxCount[buf];
-    int inf = 0;
-    for (int i = 0; i < n; ++i) {
-        Ctx& ctx = s.ctx[buf * BATCH + i];
-        const TrajEnt* tr = s.traj + (size_t)(buf * BATCH + i) * MAX_TRAJ;
-        if (ctx.terminal) {
-            if (ctx.reserved) s.nodes[ctx.leaf].flags &= ~F_PENDING;
-            backup(s, tr, ctx.trajLen, ctx.termValue);
-            continue;
-        }
-        const uint8_t typeBefore = s.nodes[ctx.leaf].type;
-        s.nodes[ctx.leaf].flags &= ~F_PENDING;
-        if (typeBefore != T_UNSOLVED) { backup(s, tr, ctx.trajLen, 0.0f); inf++; continue; }
-        const int row = rowBase + inf;
-        const float nv = shape_value(s, out->value[row], out->wdl + (size_t)row * 3, out->ml[row]);
-        backup(s, tr, ctx.trajLen, nv);
-        inf++;
+    const int lane = threadIdx.x & 63;
+    // lane c gathers context c: header, leaf type, shaped network value, and releases the leaf's reservation.
+    // (A pending leaf has no children, so no backup of this batch can pass through it or change its type, and
+    // nothing below reads F_PENDING: doing this up front is equivalent to doing it at each context's turn.)
+    int len = 0, term = 0, type = 0;
+    float val = 0.0f;
+    bool mine = lane < n;
+    if (mine) {
+        const Ctx& c = s.ctx[buf * BATCH + lane];
+        len = c.trajLen; term = c.terminal;
+        Node& ln = s.nodes[c.leaf];
+        type = ln.type;
+        if (term) { val = c.termValue; if (c.reserved) ln.flags &= ~F_PENDING; }
+        else ln.flags &= ~F_PENDING;
     }
+    const u64 nnMask = __ballot(mine && !term);                // contexts that own an inference row, in order
+    if (mine && !term && type == T_UNSOLVED) {
+        const int row = rowBase + __popcll(nnMask & ((1ULL << lane) - 1ULL));
+        val = shape_value(s, out->value[row], out->wdl + (size_t)row * 3, out->ml[row]);
+    }
+    wave_fence();
+    for (int i = 0; i < n; ++i)                                // value sums and solver propagation are order dependent
+        backup(s, s.traj + (size_t)(buf * BATCH + i) * MAX_TRAJ, ulane(len, i), ulanef(val, i), ulane(type, i));
     s.g->nodesSearched += n;
     s.g->ctxCount[buf] = 0;
     s.g->validCount[buf] = 0;
@@ -989,6 +1029,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
     const int lane = threadIdx.x & 63;
     int nctx = 0, valid = 0, attempts = 0;
     Path p;
+    TRACE_SEQ();
     while (nctx < BATCH && attempts < BATCH * 2) {
         attempts++;
         PROF_T(t0);
@@ -998,6 +1039,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
         const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
         PROF_ADD(0, t0);
         if (leaf < 0) {
+            TRACE_EV(1, p.len, 0);
             s.g->reservationCollisions++;
             cancel_virtual_losses(s, L.traj, p.len);
             continue;
@@ -1005,6 +1047,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
         bool collision = false;
         for (int i = 0; i < nctx; ++i) collision |= s.ctx[buf * BATCH + i].leaf == leaf;
         if (collision) {
+            TRACE_EV(2, p.len, 0);
             s.g->sameBatchCollisions++;
             if (reserved) s.nodes[leaf].flags &= ~F_PENDING;
             cancel_virtual_losses(s, L.traj, p.len);
@@ -1021,6 +1064,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
         const uint8_t solved = s.nodes[leaf].type;
         bool keep = true;
         if (solved != T_UNSOLVED) {
+            TRACE_EV(3, p.len, solved);
             ctx.terminal = 1;
             ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
         } else {
@@ -1029,12 +1073,14 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
             PROF_ADD(6, tk);
             if (to != 0) {
+                TRACE_EV(4, p.len, to | (endInPly << 4));
                 ctx.terminal = 1;
                 Node& ln = s.nodes[leaf];
                 if (to == 1) { ctx.termValue = 1.0f; ln.type = T_WIN; ln.valueSum = 1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
                 else if (to == 2) { ctx.termValue = -1.0f; ln.type = T_LOSS; ln.valueSum = -1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
                 else { ctx.termValue = drawValue; ln.type = T_DRAW; ln.endInPly = 1; }
             } else if (!ctx.reserved) {
+                TRACE_EV(5, p.len, 0);
                 s.g->reservationCollisions++;
                 cancel_virtual_losses(s, L.traj, p.len);
                 keep = false;
@@ -1063,6 +1109,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
                 write_planes_f16(rt, L.board, reinterpret_cast<uint4*>(planesOut + (size_t)valid * HM_PLANE_VALUES), L.pmask, L.pval);
                 PROF_ADD(26, tw);
                 PROF_ADD(7, tp);
+                TRACE_EV(6, p.len, 0);
                 valid++;
             }
         }
@@ -1188,25 +1235,6 @@ __global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, Ne
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
     PROF_FLUSH();
-}
-
-// Fused tree step of the pipelined driver: process(batch i-1) then collect(batch i+1) in ONE launch
-// (the forward of batch i runs beside it on the network stream).  activeCount[parity] is counted here,
-// activeCount[parity ^ 1] is cleared for the next launch.
-union StepLds {
-    ExpLds exp[BATCH];
-    WaveLds wave;
-};
-__global__ __launch_bounds__(64 * BATCH) void k_step(Pools pl, Params prm, NetOut out, uint16_t* planesNext, int* activeCount, int parity) {
-    __shared__ RulesTab s_rt;
-    __shared__ StepLds L;
-    if (blockIdx.x == 0 && threadIdx.x == 0) activeCount[parity ^ 1] = 0;
-    stage_table(&s_rt, pl.rules);
-    __syncthreads();
-    G s = make_view(pl, prm, blockIdx.x);
-    process_step(s, s_rt, L.exp, out, blockIdx.x, activeCount + parity);
-    if ((threadIdx.x >> 6) != 0) return;
-    (void)collect_step(s, s_rt, L.wave, planesNext, blockIdx.x);
 }
 
 // Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
@@ -1582,9 +1610,6 @@ __global__ __launch_bounds__(64) void k_rules_probe(const RulesTab* rules, const
 
 struct hm_sp;
 extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
-extern "C" int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
-                          void* d_planes_next, int parity, hipStream_t stream);
-extern "C" int hm_sp_active2_on(hm_sp* sp, int parity, int* pinned_out, hipStream_t stream);
 
 // =========================================================================================
 // host side
@@ -1601,7 +1626,6 @@ struct hm_sp {
     RootOut ro;
     u64* d_rootHash;
     int* d_active;
-    int* d_active2;
     int* d_target;
     u64* d_seed;
     uint8_t* d_mask;
@@ -1720,7 +1744,7 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * 12);
-    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_active2, 2); rc |= dalloc(sp, &sp->d_target, G_);
+    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_target, G_);
     rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
     rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
@@ -1828,26 +1852,27 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
 
+// diagnostic (-DHM_SEARCH_TRACE builds): select the traced game slot (clears the log) / read the log
+int hm_sp_trace_select(int game) {
+    unsigned int z = 0;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_traceGame), &game, sizeof game));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_traceCount), &z, sizeof z));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_traceSeq), &z, sizeof z));
+    return HM_OK;
+}
+int hm_sp_trace(unsigned long long* out, int cap) {
+    unsigned int n = 0;
+    HIPCHK(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_traceCount), sizeof n));
+    if (n > 65536u) n = 65536u;
+    const int m = (int)n < cap ? (int)n : cap;
+    if (m > 0) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * (size_t)m));
+    return (int)n;
+}
 // diagnostic (all zeros unless built with -DHM_SEARCH_PROF): out[0..31] cycles, out[32..63] counts; reset != 0 clears
 int hm_sp_profile(unsigned long long* out64, int reset) {
     if (out64) HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));
     if (reset) { unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
     return HM_OK;
-}
-// fused process(previous heads) + collect(next planes); counts active games into d_active2[parity]
-int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
-               void* d_planes_next, int parity, hipStream_t stream) {
-    NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
-             static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
-    hipLaunchKernelGGL(k_step, dim3(sp->nGames), dim3(64 * BATCH), 0, stream, sp->pl, sp->prm, o, static_cast<uint16_t*>(d_planes_next),
-                       sp->d_active2, parity & 1);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-int hm_sp_active2_on(hm_sp* sp, int parity, int* pinned_out, hipStream_t stream) {
-    HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active2 + (parity & 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    return 0;
 }
 int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream) {
     HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, stream));

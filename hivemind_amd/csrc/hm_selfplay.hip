@@ -34,9 +34,6 @@
 int hm_fail(int code, const std::string& msg);
 extern "C" int hm_sp_active(hm_sp* sp, int* active);
 extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
-extern "C" int hm_sp_step(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl, const void* d_moves_left,
-                          void* d_planes_next, int parity, hipStream_t stream);
-extern "C" int hm_sp_active2_on(hm_sp* sp, int parity, int* pinned_out, hipStream_t stream);
 
 namespace {
 
@@ -184,9 +181,6 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     constexpr int RING = 256;
     int which = 0, active = 1, iters = 0;
     const bool native = s->io.net_desc != nullptr;
-    // measured alternative: process+collect as one launch beside the forward; not faster on
-    // MI355X at 64 games because the co-running kernels slow each other down
-    static const bool fusedStep = std::getenv("HM_SELFPLAY_FUSED_STEP") != nullptr;
     if (s->evs.empty()) {
         s->evs.resize((size_t)RING * 6);
         for (auto& e : s->evs) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
@@ -232,43 +226,19 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             hipEvent_t* e = &s->evs[(size_t)(it % RING) * 6];
             float ms = 0.0f;
             const double w = native ? 8.0 : 1.0;   // each sample stands for 8 iterations
-            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += w * ms;     // fused step: process+collect launch
+            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += w * ms;
             if (hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) s->res.eval_ms += w * ms;
-            if (!(native && fusedStep) && hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += w * ms;
+            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += w * ms;
         }
         harvested = upto;
     };
     while (active > 0) {
         hipEvent_t* e = &s->evs[(size_t)(iters % RING) * 6];
-        hipEvent_t* ePrev = &s->evs[(size_t)((iters + RING - 1) % RING) * 6];
         hipEvent_t* y = &s->sync[(size_t)(iters % RING) * 2];
         hipEvent_t* yPrev = &s->sync[(size_t)((iters + RING - 1) % RING) * 2];
         const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
         const bool timed = (iters & 7) == 0;       // leg timing is sampled: event records are not free
-        if (native && fusedStep) {
-            // Pipelined form: launch i of the tree stream is ONE kernel, process(batch i-1) + collect(batch
-            // i+1); beside it the network stream runs forward(batch i).  Each launch waits only for the
-            // other stream's previous launch (its inputs), so per iteration there is a single
-            // cross-stream hand-off in each direction and no other host or device synchronisation.
-            void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
-                              {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
-            void** hPrev = hv[(iters + 1) & 1];
-            void** hCur = hv[iters & 1];
-            if (iters > 0) (void)hipStreamWaitEvent(s->sT, ePrev[3], 0);            // heads of batch i-1
-            if (timed) (void)hipEventRecord(e[0], s->sT);
-            if (int rc = hm_sp_step(s->sp, hPrev[0], hPrev[1], hPrev[2], hPrev[3], hPrev[4], s->io.planes[1 - which], iters & 1, s->sT)) return rc;
-            (void)hipEventRecord(e[1], s->sT);
-            if (iters > 0) (void)hipStreamWaitEvent(s->sN, ePrev[1], 0);            // planes[which] written by the previous tree launch
-            if (timed) (void)hipEventRecord(e[2], s->sN);
-            if (int rc = hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
-                                        hCur[0], hCur[1], hCur[2], hCur[3], hCur[4], s->sN)) return rc;
-            (void)hipEventRecord(e[3], s->sN);
-            if (poll) {
-                if (int rc = hm_sp_active2_on(s->sp, iters & 1, s->hActive, s->sT)) return rc;     // async copy + stream sync
-                active = *s->hActive;
-                (void)hipStreamSynchronize(s->sN);
-            }
-        } else if (native) {
+        if (native) {
             // tree stream: collect(next) -- net stream: forward(cur) -- tree stream: process(cur)
             void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
                               {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};

@@ -189,6 +189,18 @@ int ora_search_trace(void* sp, uint64_t* out, int cap) {
     for (int i = 0; i < n; ++i) out[i] = s->evalTrace[i];
     return (int)s->evalTrace.size();
 }
+// classify_terminal_position (searchthread.cc:101-139): outcome | endInPly << 8
+int ora_classify(void* h, int teamToPlay, int rootTeam, int rootAdv, int searchPly) {
+    int e = 0;
+    const int to = (int)classify_terminal_position(*static_cast<Board*>(h), teamToPlay, rootTeam, rootAdv != 0, searchPly, &e);
+    return to | (e << 8);
+}
+int ora_search_ctx_trace(void* sp, uint64_t* out, int cap) {
+    Search* s = static_cast<Search*>(sp);
+    int n = (int)std::min<size_t>(s->ctxTrace.size(), (size_t)cap);
+    for (int i = 0; i < n; ++i) out[i] = s->ctxTrace[i];
+    return (int)s->ctxTrace.size();
+}
 void ora_hash_evaluator(const uint16_t* planes, int n, uint16_t* value, uint16_t* piA, uint16_t* piB, uint16_t* wdl, uint16_t* ml) {
     EvalOutputs o;
     hash_evaluator(planes, n, o);

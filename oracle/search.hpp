@@ -426,6 +426,10 @@ public:
     int nodesSearched = 0, sameBatchCollisions = 0, reservationCollisions = 0, evalCalls = 0, evalRows = 0, nodeCounter = 0;
     // optional trace of every evaluated leaf hash, for step-by-step diffing against the GPU engine
     std::vector<uint64_t> evalTrace;
+    // optional per-attempt event log of collect_batch: (collect# << 32) | (code << 24) | (path length << 8) | outcome
+    std::vector<uint64_t> ctxTrace;
+    uint64_t collectSeq = 0;
+    void ev(int code, int len, int outcome) { ctxTrace.push_back((collectSeq << 32) | ((uint64_t)code << 24) | ((uint64_t)(len & 0xffff) << 8) | (uint64_t)(outcome & 0xff)); }
 
     struct Batch {
         std::vector<uint16_t> obs;
@@ -597,12 +601,14 @@ public:
         batch.validInferenceCount = 0;
         const int maxAttempts = B * 2;
         int attempts = 0;
+        collectSeq++;
         while ((int)batch.contexts.size() < B && attempts < maxAttempts) {
             attempts++;
             LeafContext ctx;
             trajectory.clear();
             LeafSel sel = select_and_expand(board, rootAdv);
             if (!sel.leaf) {
+                ev(1, (int)trajectory.size(), 0);
                 reservationCollisions++;
                 cancel_virtual_losses(trajectory);
                 unmake_trajectory(board);
@@ -610,6 +616,7 @@ public:
             }
             bool collision = std::any_of(batch.contexts.begin(), batch.contexts.end(), [&](const LeafContext& p) { return p.leaf == sel.leaf; });
             if (collision) {
+                ev(2, (int)trajectory.size(), 0);
                 sameBatchCollisions++;
                 if (sel.reserved) sel.leaf->release();
                 cancel_virtual_losses(trajectory);
@@ -625,6 +632,7 @@ public:
             NodeType solved = ctx.leaf->nodeType;
             auto drawValue = [&]() { return ctx.teamToPlay == rootTeam ? -cfg.drawContempt : cfg.drawContempt; };
             if (solved != NodeType::UNSOLVED) {
+                ev(3, (int)trajectory.size(), (int)solved);
                 ctx.isTerminal = true;
                 ctx.terminalValue = solved == NodeType::WIN ? 1.0f : solved == NodeType::LOSS ? -1.0f : drawValue();
                 batch.contexts.push_back(std::move(ctx));
@@ -634,6 +642,7 @@ public:
             int endInPly = 0;
             TerminalOutcome to = classify_terminal_position(board, ctx.teamToPlay, rootTeam, rootAdv, searchPly, &endInPly);
             if (to != TerminalOutcome::NONE) {
+                ev(4, (int)trajectory.size(), (int)to | (endInPly << 4));
                 ctx.isTerminal = true;
                 if (to == TerminalOutcome::WIN) { ctx.terminalValue = 1.0f; ctx.leaf->mark_as_win(endInPly); }
                 else if (to == TerminalOutcome::LOSS) { ctx.terminalValue = -1.0f; ctx.leaf->mark_as_loss(endInPly); }
@@ -644,6 +653,7 @@ public:
             }
             ctx.isTerminal = false;
             if (!ctx.hasReservation) {
+                ev(5, (int)trajectory.size(), 0);
                 reservationCollisions++;
                 cancel_virtual_losses(trajectory);
                 unmake_trajectory(board);
@@ -654,6 +664,7 @@ public:
             hm_board cb;
             board.to_compact(&cb, ctx.teamToPlay, ctx.sitPlaneActive);
             planes_f16(cb, batch.obs.data() + (size_t)batch.validInferenceCount * HM_PLANE_VALUES);
+            ev(6, (int)trajectory.size(), 0);
             batch.validInferenceCount++;
             batch.contexts.push_back(std::move(ctx));
             unmake_trajectory(board);

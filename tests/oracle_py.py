@@ -176,6 +176,8 @@ lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp
 lib.ora_search_root_q.restype, lib.ora_search_root_q.argtypes = C.c_float, [_vp]
 lib.ora_search_info.restype, lib.ora_search_info.argtypes = None, [_vp, _vp]
 lib.ora_search_trace.restype, lib.ora_search_trace.argtypes = _i, [_vp, _vp, _i]
+lib.ora_classify.restype, lib.ora_classify.argtypes = _i, [_vp, _i, _i, _i, _i]
+lib.ora_search_ctx_trace.restype, lib.ora_search_ctx_trace.argtypes = _i, [_vp, _vp, _i]
 lib.ora_hash_evaluator.restype, lib.ora_hash_evaluator.argtypes = None, [_vp, _i, _vp, _vp, _vp, _vp, _vp]
 lib.ora_pw_allowed_children.restype, lib.ora_pw_allowed_children.argtypes = _i, [_i, _i]
 lib.ora_get_cpuct.restype, lib.ora_get_cpuct.argtypes = C.c_float, [C.c_float]
@@ -211,6 +213,15 @@ class Search:
 
     def run(self, board, team, adv, nodes):
         return bool(lib.ora_search_run(self.h, board.h, team, int(adv), nodes))
+
+    def ctx_trace(self):
+        """collect_batch event log: rows of (collect#, code, path length, outcome); codes: 1 no leaf, 2 same-batch
+        collision, 3 solved leaf, 4 classified terminal, 5 leaf not reserved, 6 network leaf."""
+        cap = 1 << 16
+        buf = np.zeros(cap, np.uint64)
+        n = min(lib.ora_search_ctx_trace(self.h, buf.ctypes.data, cap), cap)
+        v = buf[:n]
+        return np.stack([(v >> np.uint64(32)), (v >> np.uint64(24)) & np.uint64(0xff), (v >> np.uint64(8)) & np.uint64(0xffff), v & np.uint64(0xff)], axis=1).astype(np.int64)
 
     def edges(self):
         cap = 1024

@@ -29,6 +29,10 @@ def test_rules_probe_matches_oracle(hm):
         assert [bool(x) for x in out[i, :6]] == want, i
         assert int(keys[i, 0]) == b.hash_key(False) and int(keys[i, 1]) == b.hash_key(True), i
         assert int(keys[i, 2]) == int(O.lib.ora_rep_key(b.h, 0)) and int(keys[i, 3]) == int(O.lib.ora_rep_key(b.h, 1))
+        # classify_terminal_position at search ply 1 for either team to play (incl. the waiting-board mate rule)
+        team, adv = int(boards["team"][i]), int(boards["time_adv"][i])
+        assert int(out[i, 6]) == int(O.lib.ora_classify(b.h, team, team, adv, 1)), (i, "classify own")
+        assert int(out[i, 7]) == int(O.lib.ora_classify(b.h, team ^ 1, team, adv, 1)), (i, "classify other")
 
 
 def _roots(n, seed):
