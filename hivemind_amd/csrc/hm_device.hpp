@@ -243,9 +243,7 @@ constexpr u32 ILLEGAL_FLAG = 0x80000000u;
 // Ordered legal move list (generate<LEGAL>), written to out[0..n).  `out` may point to LDS
 // or global memory.  Returns n.  Pseudo-legal moves are emitted in the reference's order with
 // an illegal flag, then compacted with the reference's swap-with-last rule (movegen.cpp:449-453).
-// `p` is taken by value: the generator is a real call (not inlined), and a by-reference argument would pin
-// the caller's position in scratch memory for its whole lifetime.
-__device__ __attribute__((noinline)) int gen_legal(const AttackTab& t, const P p, u32* out) {
+__device__ __forceinline__ int gen_legal_body(const AttackTab& t, const P& p, u32* out) {
     Analysis an;
     analyse(t, p, an);
     const int us = p.stm, them = us ^ 1, k = an.ksq;
@@ -372,6 +370,24 @@ __device__ __attribute__((noinline)) int gen_legal(const AttackTab& t, const P p
         else ++cur;
     }
     return n;
+}
+// The generator is a real call (not inlined into its many call sites).  `p` is taken by value — a by-reference
+// argument would pin the caller's position in scratch memory for its whole lifetime — and the attack tables
+// (always staged in LDS) and, for gen_legal, the output list travel as LDS pointers so that the body compiles
+// to ds_read/ds_write instead of flat accesses.  gen_legal_to is the form for lists in global memory.
+typedef const __attribute__((address_space(3))) AttackTab* LdsAttackTab;
+typedef __attribute__((address_space(3))) u32* LdsList;
+__device__ __attribute__((noinline)) int gen_legal_lds(LdsAttackTab t, const P p, LdsList out) {
+    return gen_legal_body(*(const AttackTab*)t, p, (u32*)out);
+}
+__device__ __attribute__((noinline)) int gen_legal_glb(LdsAttackTab t, const P p, u32* out) {
+    return gen_legal_body(*(const AttackTab*)t, p, out);
+}
+__device__ __forceinline__ int gen_legal(const AttackTab& t, const P& p, u32* out) {          // out in LDS
+    return gen_legal_lds((LdsAttackTab)&t, p, (LdsList)out);
+}
+__device__ __forceinline__ int gen_legal_to(const AttackTab& t, const P& p, u32* out) {       // out anywhere
+    return gen_legal_glb((LdsAttackTab)&t, p, out);
 }
 
 // Legal move COUNT only (bulk counting at perft leaves): same set as gen_legal, no list.

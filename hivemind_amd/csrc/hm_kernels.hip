@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void legal_moves_kernel(const DeviceTables* __
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         P p;
         load_pos(p, pos + i);
-        counts[i] = (u32)gen_legal(s_att, p, moves + i * HM_MAX_MOVES);
+        counts[i] = (u32)gen_legal_to(s_att, p, moves + i * HM_MAX_MOVES);
     }
 }
 
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void perft_lists_kernel(const DeviceTables* __
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * n; t += (size_t)gridDim.x * blockDim.x) {
         P p;
         load_pos(p, (t & 1) ? &front[t >> 1].b : &front[t >> 1].a);
-        gen_legal(s_att, p, lists + t * HM_MAX_MOVES);
+        gen_legal_to(s_att, p, lists + t * HM_MAX_MOVES);
     }
 }
 
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256) void perft_leaf2_kernel(const DeviceTables* __
         P A, B;
         load_pos(A, &front[i].a);
         load_pos(B, &front[i].b);
-        const int ca = gen_legal(s_att, A, la);
-        const int cb = gen_legal(s_att, B, lb);
+        const int ca = gen_legal_to(s_att, A, la);
+        const int cb = gen_legal_to(s_att, B, lb);
         for (int x = 0; x < ca; ++x) {
             P A1 = A;
             const u32 ma = la[x];

@@ -29,6 +29,8 @@ struct RulesTab {
     uint16_t r50_f16[64];      // min(r50,50)/50 as fp16 (planes.cc:202-205)
 };
 
+typedef const __attribute__((address_space(3))) RulesTab* LdsRulesTab;   // real calls take the LDS-staged tables as LDS pointers
+
 constexpr u64 HISTORY_HASH_SEED = 0xcbf29ce484222325ULL;
 __device__ __forceinline__ u64 mix_hash(u64 key, u64 value) {   // board.h:126-131
     value += 0x9e3779b97f4a7c15ULL;
@@ -121,7 +123,9 @@ __device__ inline bool has_useful_capture(const RulesTab& t, const P& q, int par
 }
 
 // board.cc:214-314.  bd[0], bd[1] = BOARD_A, BOARD_B.  scratch: 2 lists of HM_MAX_MOVES.
-__device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, const P bdA, const P bdB, int boardInCheck, int checkedSide, bool adv, u32* scratch) {
+__device__ __attribute__((noinline)) bool can_partner_blocking_scan(LdsRulesTab tl, const P bdA, const P bdB, int boardInCheck, int checkedSide, bool adv, LdsList scratchl) {
+    const RulesTab& t = *(const RulesTab*)tl;
+    u32* scratch = (u32*)scratchl;
     // by-value copies: callers keep their positions in registers
     const P p = boardInCheck ? bdB : bdA, partner = boardInCheck ? bdA : bdB;
     const int partnerSide = checkedSide ^ 1;
@@ -149,6 +153,11 @@ __device__ inline bool can_partner_provide_blocking_piece(const RulesTab& t, con
     return true;
 }
 
+// (a real call: reached only for a board that is in check without a legal move)
+__device__ __forceinline__ bool can_partner_provide_blocking_piece(const RulesTab& t, const P& bdA, const P& bdB, int boardInCheck, int checkedSide, bool adv, u32* scratch) {
+    return can_partner_blocking_scan((LdsRulesTab)&t, bdA, bdB, boardInCheck, checkedSide, adv, (LdsList)scratch);
+}
+
 // Legal move counts of both boards, computed by lanes 0 and 1 concurrently (wave-uniform call).
 __device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, int& cntB) {
     const int lane = threadIdx.x & 63;
@@ -173,8 +182,11 @@ __device__ inline bool is_checkmate_c(const RulesTab& t, const P* bd, int side, 
     return false;
 }
 
-// board.cc:169-208.  scratch: 2 lists.  Safe in lane-divergent code (no cross-lane operations).
-__device__ inline bool is_checkmate(const RulesTab& t, const P* bd, int side, bool adv, u32* scratch) {
+// board.cc:169-208.  scratch: 2 lists.  Safe in lane-divergent code (no cross-lane operations).  A real call.
+__device__ __attribute__((noinline)) bool is_checkmate_scan(LdsRulesTab tl, const P bdA, const P bdB, int side, bool adv, LdsList scratchl) {
+    const RulesTab& t = *(const RulesTab*)tl;
+    u32* scratch = (u32*)scratchl;
+    const P bd[2] = {bdA, bdB};
     const bool onA = (int)bd[0].stm == side, onB = (int)bd[1].stm == (side ^ 1);
     int cntA = -1, cntB = -1;
     if (onA) {
@@ -190,6 +202,10 @@ __device__ inline bool is_checkmate(const RulesTab& t, const P* bd, int side, bo
         if (!movesA && !movesB && (!adv || (onA && onB))) return true;
     }
     return false;
+}
+
+__device__ __forceinline__ bool is_checkmate(const RulesTab& t, const P* bd, int side, bool adv, u32* scratch) {
+    return is_checkmate_scan((LdsRulesTab)&t, bd[0], bd[1], side, adv, (LdsList)scratch);
 }
 
 __device__ __forceinline__ bool is_double_sit_legal(bool adv, bool aOn, bool bOn) { return adv && (aOn != bOn); }          // joint_action.h:14-18
@@ -272,7 +288,10 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
 // reply needs the history with that reply's key appended, handled on the fly.
 // A real call with the joint position passed by value: the rule is heavy (lane-parallel mate scan, nested
 // checkmate tests) and inlining it into the traversal kernel drives that kernel to the 512-VGPR limit.
-__device__ __attribute__((noinline)) bool waiting_board_mate_scan(const RulesTab& t, const JBoard j, int team, bool adv, int searchPly, u32* scratch) {
+// (tables and scratch lists travel as LDS pointers so the body keeps ds_read/ds_write accesses).
+__device__ __attribute__((noinline)) bool waiting_board_mate_scan(LdsRulesTab tl, const JBoard j, int team, bool adv, int searchPly, LdsList scratchl) {
+    const RulesTab& t = *(const RulesTab*)tl;
+    u32* scratch = (u32*)scratchl;
     const bool aOn = (int)j.bd[0].stm == team;
     const int active = aOn ? 0 : 1, waiting = 1 - active;
     u32* mating = scratch;
@@ -340,7 +359,7 @@ __device__ __attribute__((noinline)) bool waiting_board_mate_scan(const RulesTab
 __device__ __forceinline__ bool has_unavoidable_waiting_board_mate(const RulesTab& t, const JBoard& j, int team, bool adv, int searchPly, u32* scratch) {
     const bool aOn = (int)j.bd[0].stm == team, bOn = (int)j.bd[1].stm == (team ^ 1);
     if (aOn == bOn) return false;                     // the rule needs exactly one board on turn
-    return waiting_board_mate_scan(t, j, team, adv, searchPly, scratch);
+    return waiting_board_mate_scan((LdsRulesTab)&t, j, team, adv, searchPly, (LdsList)scratch);
 }
 
 // searchthread.cc:101-139.  Returns 0 NONE, 1 WIN, 2 LOSS, 3 DRAW (== NodeType numbering).

@@ -338,25 +338,49 @@ __device__ inline Edge* edge_append(G& s, Node& n) {
     return edges_of(s, n) + n.expanded;
 }
 
-// node.h:151-175 — edges scanned lane-parallel (one edge per lane), wave-reduced
-__device__ inline bool should_expand_new_child(G& s, const Node& n) {
+// One lane-parallel pass over a node's edges (lane i holds edge i, then i+64, ...) feeds both the widening test
+// (node.h:151-175) and PUCT selection (node.cc:6-119): per edge the child's solver type is gathered once, the
+// wave reductions give "all children lose", "some child unvisited" and the visited prior mass, and the first 64
+// edges stay in registers for the arg-max.
+struct EdgeScan {
+    Edge ed;                 // this lane's edge of chunk 0 (valid when lane < expanded)
+    int ct;                  // its child's node type
+    bool anyNonLosing, anyUnvisited;
+    float visitedPolicySum;  // priors of edges with visits + virtual losses > 0, added in index order
+    int visits;              // parent visits incl. virtual visits
+};
+__device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
     const int lane = threadIdx.x & 63;
-    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    const int limit = n.expanded;
     const Edge* e = edges_of(s, n);
-    bool allLose = true, anyUnvisited = false;
-    for (int base = 0; base < n.expanded; base += 64) {
+    o.visits = n.visits + n.vvsum;
+    o.anyNonLosing = false; o.anyUnvisited = false; o.visitedPolicySum = 0.0f;
+    o.ct = T_UNSOLVED;
+    const bool dynFpu = s.prm->enableDynamicFpu && o.visits > 0;
+    for (int base = 0; base < limit; base += 64) {
         const int i = base + lane;
-        if (i < n.expanded) {
-            const int child = e[i].child;
-            const int ev = e[i].visits + e[i].vloss;
-            allLose &= s.nodes[child].type == T_WIN;
-            anyUnvisited |= ev == 0;
+        float pr = 0.0f;
+        bool counted = false, nonLosing = false, unvisited = false;
+        if (i < limit) {
+            const Edge ed = e[i];
+            const int ct = s.nodes[ed.child].type;
+            if (base == 0) { o.ed = ed; o.ct = ct; }
+            pr = ed.prior;
+            const bool touched = ed.visits + ed.vloss > 0;
+            counted = dynFpu && touched;
+            unvisited = !touched;
+            nonLosing = ct != T_WIN;
         }
+        o.anyNonLosing |= wave_any(nonLosing);
+        o.anyUnvisited |= wave_any(unvisited);
+        for (u64 m = __ballot(counted); m; m &= m - 1) o.visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
     }
-    allLose = n.expanded > 0 && wave_all(allLose);
-    anyUnvisited = wave_any(anyUnvisited);
+}
+__device__ inline bool should_expand_new_child(G& s, const Node& n, const EdgeScan& sc) {
+    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    const bool allLose = n.expanded > 0 && !sc.anyNonLosing;
     if (hasNext && allLose) return true;
-    if (anyUnvisited) return false;
+    if (sc.anyUnvisited) return false;
     int v = n.visits + n.vvsum;
     if (v < 0) v = 0;
     if (v >= MAX_VISITS_TAB) v = MAX_VISITS_TAB - 1;
@@ -465,45 +489,22 @@ __device__ inline void cancel_virtual_losses(G& s, const TrajEnt* tr, int len) {
 
 // node.cc:6-119 — lane-parallel PUCT: lane i scores edge i (+64k), wave arg-max, lowest index wins ties.
 struct Sel { int child, idx; bool reserved; int pending; };
-__device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64* unavailMask /*LDS, 8 words*/) {
+__device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, const Node& n, const EdgeScan& sc, u64* unavailMask /*LDS, 8 words*/) {
     const int lane = threadIdx.x & 63;
-    Node n = s.nodes[nodeId];
     const int limit = n.expanded;
     if (limit == 0) return {-1, -1, false, -1};
     Edge* e = edges_of(s, n);
-    int visits = n.visits + n.vvsum;
+    const int visits = sc.visits;
     const float sqrtVisits = sqrtf((float)visits);
     int vi = visits < 0 ? 0 : (visits >= MAX_VISITS_TAB ? MAX_VISITS_TAB - 1 : visits);
     const float c = s.pl->cpuctTab[vi];
     const float explorationBase = c * sqrtVisits;
-    float visitedPolicySum = 0.0f;
-    bool hasNonLosing = false;
-    PROF_T(tq1);
-    // edges are loaded lane-parallel; the prior sum is then accumulated in index order (the
-    // reference adds childPriors in a plain loop) from registers via shuffles
-    for (int base = 0; base < limit; base += 64) {
-        const int i = base + lane;
-        float pr = 0.0f;
-        bool counted = false, nonLosing = false;
-        if (i < limit) {
-            const Edge ed = e[i];
-            pr = ed.prior;
-            counted = s.prm->enableDynamicFpu && visits > 0 && (ed.visits + ed.vloss > 0);
-            nonLosing = s.nodes[ed.child].type != T_WIN;
-        }
-        hasNonLosing |= wave_any(nonLosing);
-        const u64 cmask = __ballot(counted);
-        const int cnt = limit - base < 64 ? limit - base : 64;
-        (void)cnt;
-        for (u64 m = cmask; m; m &= m - 1) visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
-    }
-    hasNonLosing &= n.type == T_UNSOLVED;
+    const bool hasNonLosing = sc.anyNonLosing && n.type == T_UNSOLVED;
     const float parentQ = visits > 0 ? (n.valueSum / (float)visits) : 0.0f;
     const float fpuQ = (s.prm->enableDynamicFpu && visits > 0)
-        ? clampf(parentQ - s.prm->fpuReduction * sqrtf(fmaxf(0.0f, visitedPolicySum)), -1.0f, 1.0f) : Q_INIT;
+        ? clampf(parentQ - s.prm->fpuReduction * sqrtf(fmaxf(0.0f, sc.visitedPolicySum)), -1.0f, 1.0f) : Q_INIT;
     for (int w = 0; w < 8; ++w) unavailMask[w] = 0;
     int pending = -1;
-    PROF_ADD(19, tq1);
     PROF_T(tq2);
     while (true) {
         float bestScore = -INFINITY;
@@ -513,9 +514,11 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
             float score = -INFINITY;
             bool ok = i < limit;
             if (ok) {
-                const Edge ed = e[i];
+                Edge ed = sc.ed;
+                int ct = sc.ct;
+                if (base != 0) { ed = e[i]; ct = s.nodes[ed.child].type; }      // beyond the cached chunk (rare)
                 if ((unavailMask[i >> 6] >> (i & 63)) & 1) ok = false;
-                else if (hasNonLosing && s.nodes[ed.child].type == T_WIN) ok = false;
+                else if (hasNonLosing && ct == T_WIN) ok = false;
                 else {
                     const int vl = ed.vloss;
                     const uint32_t ne = (uint32_t)ed.visits + (uint32_t)vl;
@@ -528,18 +531,18 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, u64*
                 }
             }
             // wave arg-max of (score, lowest index).  `score > best` semantic: NaN / -inf never win.
-            float sc = ok ? score : -INFINITY;
-            int id = ok && sc > -INFINITY ? i : 0x7fffffff;
+            float scv = ok ? score : -INFINITY;
+            int id = ok && scv > -INFINITY ? i : 0x7fffffff;
             for (int off = 32; off > 0; off >>= 1) {
-                const float osc = __shfl_xor(sc, off);
+                const float osc = __shfl_xor(scv, off);
                 const int oid = __shfl_xor(id, off);
-                if (osc > sc || (osc == sc && oid < id)) { sc = osc; id = oid; }
+                if (osc > scv || (osc == scv && oid < id)) { scv = osc; id = oid; }
             }
-            sc = ufirstf(sc); id = ufirst(id);
-            if (id != 0x7fffffff && sc > bestScore) { bestScore = sc; bestIdx = id; }
+            scv = ufirstf(scv); id = ufirst(id);
+            if (id != 0x7fffffff && scv > bestScore) { bestScore = scv; bestIdx = id; }
         }
         if (bestIdx < 0) return {-1, -1, false, pending};
-        const int child = e[bestIdx].child;
+        const int child = bestIdx < 64 ? ulane(sc.ed.child, bestIdx) : e[bestIdx].child;
         Node& cn = s.nodes[child];
         bool reserved = false;
         if (!(cn.flags & F_EXPANDED) && cn.type == T_UNSOLVED) {
@@ -623,7 +626,9 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         if (p.len >= MAX_TRAJ - 1) { s.g->overflow |= 4; return -1; }
         int next = -1, childIdx = -1;
         PROF_T(tw);
-        const bool widen = should_expand_new_child(s, n);
+        EdgeScan sc;
+        scan_edges(s, n, sc);
+        const bool widen = should_expand_new_child(s, n, sc);
         PROF_ADD(1, tw);
         if (widen) {
             // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
@@ -665,7 +670,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             }
         }
         PROF_T(ts);
-        const Sel sel = select_child_and_apply_virtual_loss(s, cur, unavailMask);
+        const Sel sel = select_child_and_apply_virtual_loss(s, cur, n, sc, unavailMask);
         PROF_ADD(3, ts);
         if (sel.child < 0 || sel.idx < 0) return -1;
         next = sel.child; childIdx = sel.idx; reserved = sel.reserved;

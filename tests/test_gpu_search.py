@@ -40,10 +40,14 @@ def _roots(n, seed):
     return boards
 
 
-@pytest.mark.parametrize("nodes,noise", [(400, False), (400, True), (100, False), (1600, True)])
+@pytest.mark.parametrize("nodes,noise", [(400, False), (400, True), (100, False), (1600, True), (200, "sweep")])
 def test_search_matches_oracle(hm, nodes, noise):
     G = 24 if nodes <= 400 else 8           # BASELINE configs[4]: nodes=1600, transposition-sharing MCGS + Dirichlet noise
-    roots = _roots(G, 77 + nodes)
+    if noise == "sweep":                    # many more roots (late-game positions included): rare rules get exercised
+        G, noise = 128, True
+        roots = O.random_positions(4242, G * 11, 160)[::11][:G].copy()
+    else:
+        roots = _roots(G, 77 + nodes)
     roots[0] = O.Board().compact(0, False)[0]
     eng = hm.SearchEngine(G, 1700)
     eng.set_games(roots)
