@@ -759,7 +759,8 @@ struct WaveLds {
         u32 lists[NLISTS][HM_MAX_MOVES];
         ExpLds exp;
     };
-    u64 board[26];
+    u64 board[BATCH][26];    // hm_board images of this batch's network leaves, handed to the plane-writer wave
+    int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
     u64 unavail[8];
@@ -1097,7 +1098,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
                 store_pos(&ctx.pos[1], p.jb.bd[1]);
                 // hm_board image in LDS for the plane writer
                 wave_fence();
-                hm_board* hb = reinterpret_cast<hm_board*>(L.board);
+                hm_board* hb = reinterpret_cast<hm_board*>(L.board[valid]);
                 const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
                 if (lane == 0) {
                     hb->pos[0] = ctx.pos[0]; hb->pos[1] = ctx.pos[1];
@@ -1111,7 +1112,9 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
                 wave_fence();
                 PROF_ADD(25, tp);
                 PROF_T(tw);
-                write_planes_f16(rt, L.board, reinterpret_cast<uint4*>(planesOut + (size_t)valid * HM_PLANE_VALUES), L.pmask, L.pval);
+                // the planes are written by the second wave of the block while this one goes on selecting
+                if (lane == 0) __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)planesOut;
                 PROF_ADD(26, tw);
                 PROF_ADD(7, tp);
                 TRACE_EV(6, p.len, 0);
@@ -1215,19 +1218,40 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
     PROF_ADD(12, te);
 }
 
-__global__ __launch_bounds__(64) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
+// Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
+// posts in LDS into fp16 planes, so the 9.4 KB plane writes overlap the next descent instead of extending it.
+__global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     PROF_INIT();
     PROF_T(ta);
     stage_table(&s_rt, pl.rules);
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; }
     __syncthreads();
     PROF_ADD(9, ta);
-    G s = make_view(pl, prm, blockIdx.x);
-    const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
-    if (rowsNext && threadIdx.x == 0) rowsNext[blockIdx.x] = rows;     // batch size of this game for the evaluator
-    PROF_ADD(10, ta);
+    if (threadIdx.x < 64) {
+        G s = make_view(pl, prm, blockIdx.x);
+        const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
+        if (threadIdx.x == 0) {
+            if (rowsNext) rowsNext[blockIdx.x] = rows;             // batch size of this game for the evaluator
+            __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        PROF_ADD(10, ta);
+    } else {
+        uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
+        int served = 0;
+        for (;;) {                                                 // ends once wave 0 has set `done` and every post is served
+            int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (served >= posted) {
+                if (!__hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(4); continue; }
+                posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (served >= posted) break;
+            }
+            write_planes_f16(s_rt, L.board[served], reinterpret_cast<uint4*>(dst + (size_t)served * HM_PLANE_VALUES), L.pmask, L.pval);
+            served++;
+        }
+    }
     PROF_FLUSH();
 }
 
@@ -1817,7 +1841,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
 
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
-    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(128), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
                        static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
