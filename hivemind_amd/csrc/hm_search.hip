@@ -327,6 +327,13 @@ __device__ inline bool gen_next(G& s, GenHdr& h, HeapEnt* out) {   // getNext :3
     return true;
 }
 
+// Node::flags lives in the dword at byte 48 (depth:16, team:8, flags:8).  k_process expands leaves (sets
+// F_EXPANDED) and retires reservations (clears F_PENDING) from different waves at once: word atomics.
+__device__ __forceinline__ unsigned int* flags_word(Node* n) { return reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(n) + 48); }
+static_assert(offsetof(Node, flags) == 51, "Node::flags moved: fix flags_word");
+__device__ __forceinline__ void node_set_flag(Node* n, unsigned int f) { atomicOr(flags_word(n), f << 24); }
+__device__ __forceinline__ void node_clear_flag(Node* n, unsigned int f) { atomicAnd(flags_word(n), ~(f << 24)); }
+
 // ---- edges -------------------------------------------------------------------------------
 __device__ inline Edge* edge_append(G& s, Node& n) {
     if (n.edgeCap == 0) {
@@ -932,7 +939,11 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         }
     }
     *reinterpret_cast<GenHdr*>(s.arena + genOff) = h;
-    s.nodes[ctx.leaf] = leaf;
+    // only the fields expansion owns: the backups of this batch update visits / value sum of the same node concurrently
+    Node* np = &s.nodes[ctx.leaf];
+    np->gen = leaf.gen; np->edges = leaf.edges; np->edgeCap = leaf.edgeCap; np->expanded = leaf.expanded;
+    wave_fence();
+    if ((leaf.flags & F_EXPANDED) && lane == 0) node_set_flag(np, F_EXPANDED);
     PROF_ADD(24, te4);
 }
 
@@ -993,8 +1004,8 @@ __device__ inline void backup_batch(G& s, int buf, const NetOut* out, int rowBas
         len = c.trajLen; term = c.terminal;
         Node& ln = s.nodes[c.leaf];
         type = ln.type;
-        if (term) { val = c.termValue; if (c.reserved) ln.flags &= ~F_PENDING; }
-        else ln.flags &= ~F_PENDING;
+        if (term) { val = c.termValue; if (c.reserved) node_clear_flag(&ln, F_PENDING); }
+        else node_clear_flag(&ln, F_PENDING);
     }
     const u64 nnMask = __ballot(mine && !term);                // contexts that own an inference row, in order
     if (mine && !term && type == T_UNSOLVED) {
@@ -1182,32 +1193,37 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
         return;
     }
     const int pending = s.g->pending;
+    const int nctx = pending >= 0 ? s.g->ctxCount[pending] : 0;
     const bool solvedOrOverflow = s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow;
     const bool doProcess = pending >= 0 && !(st == ST_FINISHING && solvedOrOverflow);
-    // phase A: one leaf expansion per wave
+    __syncthreads();                                           // every wave holds the batch header before wave 0 retires it
+    // Expansions (waves 1..8, one leaf each) and the ordered backups (wave 0) touch disjoint state — a pending leaf
+    // has no children, so no path of this batch runs through one, and the two sides write different fields of the
+    // leaf nodes — and run side by side.
     PROF_T(te);
-    if (doProcess && wave < s.g->ctxCount[pending]) expand_context(s, rt, exp[wave], pending, wave, rootTeam, rootAdv, &out, rowBase);
+    if (wave == 0) {
+        if (pending >= 0) {
+            PROF_T(tb);
+            if (st == ST_FINISHING && solvedOrOverflow) abort_batch(s, pending);   // discard_pending_iteration (agent.cc:343-352)
+            else backup_batch(s, pending, &out, rowBase);
+            PROF_ADD(14, tb);
+        }
+    } else if (doProcess && wave - 1 < nctx) {
+        expand_context(s, rt, exp[wave - 1], pending, wave - 1, rootTeam, rootAdv, &out, rowBase);
+    }
     __threadfence_block();
     __syncthreads();
     PROF_ADD(11, te);
     if (wave == 0) {
-        // phase B (wave 0): ordered backups and the run_iteration / finish_pending tail
+        // run_iteration / finish_pending tail
         if (st == ST_FINISHING) {
-            // finish_pending_iteration / discard_pending_iteration (agent.cc:343-352)
-            if (pending >= 0) {
-                s.g->pending = -1;
-                if (solvedOrOverflow) abort_batch(s, pending);
-                else backup_batch(s, pending, &out, rowBase);
-            }
+            if (pending >= 0) s.g->pending = -1;
             s.g->status = s.g->overflow ? ST_ERROR : ST_DONE;
         } else if (pending < 0) {
             if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
         } else {
             const int look = 1 - pending;
             s.g->pending = -1;
-            PROF_T(tb);
-            backup_batch(s, pending, &out, rowBase);
-            PROF_ADD(14, tb);
             if (s.g->validCount[look] == 0) process_batch(s, rt, exp[0], look, rootTeam, rootAdv, nullptr, 0);
             else s.g->pending = look;
             if ((threadIdx.x & 63) == 0) atomicAdd(activeCount, 1);
@@ -1255,7 +1271,7 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
     PROF_FLUSH();
 }
 
-__global__ __launch_bounds__(64 * BATCH) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
+__global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params prm, NetOut out, int* activeCount) {
     __shared__ RulesTab s_rt;
     __shared__ ExpLds s_exp[BATCH];
     PROF_INIT();
@@ -1854,7 +1870,7 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
     hipStream_t st = static_cast<hipStream_t>(stream);
     NetOut o{static_cast<const uint16_t*>(d_value), static_cast<const uint16_t*>(d_pi_a), static_cast<const uint16_t*>(d_pi_b),
              static_cast<const uint16_t*>(d_wdl), static_cast<const uint16_t*>(d_moves_left)};
-    hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64 * BATCH), 0, st, sp->pl, sp->prm, o, sp->d_active);
+    hipLaunchKernelGGL(k_process, dim3(sp->nGames), dim3(64 * (BATCH + 1)), 0, st, sp->pl, sp->prm, o, sp->d_active);
     HIPCHK(hipGetLastError());
     if (active_games) {
         HIPCHK(hipMemcpyAsync(active_games, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, st));
