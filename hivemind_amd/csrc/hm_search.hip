@@ -244,11 +244,6 @@ __device__ inline int tt_insert_or_get(G& s, u64 hash, int node) {
 }
 
 // ---- candidate generator (joint_action.h:126-359), strict total order --------------------
-__device__ __forceinline__ bool heap_before(const HeapEnt& a, const HeapEnt& b) {   // a pops before b
-    if (a.prio != b.prio) return a.prio > b.prio;
-    if (a.iA != b.iA) return a.iA < b.iA;
-    return a.iB < b.iB;
-}
 __device__ inline float joint_prior(const G& s, const GenHdr& h, int iA, int iB, u32* mA, u32* mB) {   // JointActionCandidate ctor :80-105
     const u32 a = reinterpret_cast<const u32*>(s.arena + h.movesA)[iA], b = reinterpret_cast<const u32*>(s.arena + h.movesB)[iB];
     const float pA = reinterpret_cast<const float*>(s.arena + h.priorsA)[iA], pB = reinterpret_cast<const float*>(s.arena + h.priorsB)[iB];
@@ -290,15 +285,9 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCand
         if (jp >= 0.0f) {
             if (h.heapSize >= h.heapCap) gen_grow(s, h.heap, h.heapCap, h.heapSize, 8);
             if (h.heapSize >= h.heapCap) return;
-            HeapEnt* hp = reinterpret_cast<HeapEnt*>(s.arena + h.heap);
-            HeapEnt e{jp, (uint16_t)a, (uint16_t)b};
-            u32 i = h.heapSize++;
-            while (i > 0) {                                   // sift up
-                const u32 par = (i - 1) >> 1;
-                if (!heap_before(e, hp[par])) break;
-                hp[i] = hp[par]; i = par;
-            }
-            hp[i] = e;
+            // the frontier is an unordered array: the pop below takes the arg-best of the strict total order, which
+            // is exactly the element a binary heap with that comparator would pop
+            reinterpret_cast<HeapEnt*>(s.arena + h.heap)[h.heapSize++] = HeapEnt{jp, (uint16_t)a, (uint16_t)b};
         } else if (sp + 2 <= 64) {
             // the reference recurses (iA+1,iB) first, then (iA,iB+1): push in reverse for LIFO
             stack[sp++] = ((u32)a << 16) | (u32)(b + 1);
@@ -308,19 +297,28 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCand
 }
 __device__ inline bool gen_next(G& s, GenHdr& h, HeapEnt* out) {   // getNext :312-328
     if (h.heapSize == 0) return false;
+    const int lane = threadIdx.x & 63;
     HeapEnt* hp = reinterpret_cast<HeapEnt*>(s.arena + h.heap);
-    const HeapEnt best = hp[0];
-    const HeapEnt last = hp[--h.heapSize];
-    u32 i = 0;
     const u32 n = h.heapSize;
-    while (true) {                                            // sift down
-        u32 c = 2 * i + 1;
-        if (c >= n) break;
-        if (c + 1 < n && heap_before(hp[c + 1], hp[c])) ++c;
-        if (!heap_before(hp[c], last)) break;
-        hp[i] = hp[c]; i = c;
+    // lane-parallel arg-best over the frontier: (prior desc, iA asc, iB asc) is a strict total order
+    float bp = -INFINITY; u32 bk = 0xffffffffu; int bi = -1;
+    for (u32 base = 0; base < n; base += 64) {
+        const u32 i = base + lane;
+        float pr = -INFINITY; u32 key = 0xffffffffu; int idx = -1;
+        if (i < n) { const HeapEnt e = hp[i]; pr = e.prio; key = ((u32)e.iA << 16) | (u32)e.iB; idx = (int)i; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float op = __shfl_xor(pr, off);
+            const u32 ok = (u32)__shfl_xor((int)key, off);
+            const int oi = __shfl_xor(idx, off);
+            if (oi >= 0 && (idx < 0 || op > pr || (op == pr && ok < key))) { pr = op; key = ok; idx = oi; }
+        }
+        pr = ufirstf(pr); key = (u32)ufirst((int)key); idx = ufirst(idx);
+        if (idx >= 0 && (bi < 0 || pr > bp || (pr == bp && key < bk))) { bp = pr; bk = key; bi = idx; }
     }
-    if (n > 0) hp[i] = last;
+    const HeapEnt best{bp, (uint16_t)(bk >> 16), (uint16_t)(bk & 0xffffu)};
+    h.heapSize = n - 1;
+    if ((u32)bi != n - 1) hp[bi] = hp[n - 1];
+    wave_fence();
     gen_push(s, h, best.iA + 1, best.iB);
     gen_push(s, h, best.iA, best.iB + 1);
     *out = best;
