@@ -98,6 +98,20 @@ def cpu_selfplay_baseline(model, nodes, seconds=20.0):
                        f"({torch.get_num_threads()} intra-op threads); {nodes_done / dt:.0f} nodes/s")
 
 
+def _pmc_traffic(path):
+    """bytes per launch by kernel = WRITE_SIZE + corrected FETCH_SIZE of a committed rocprofv3 PMC summary."""
+    full = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
+    out = {}
+    try:
+        rows = json.load(open(full))
+        rows = rows["rows"] if isinstance(rows, dict) else rows
+        for r in rows:
+            out[r["kernel"]] = out.get(r["kernel"], 0.0) + float(r["avg_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,6 +223,13 @@ def main():
         roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_collect (tree traversal)", "kernel_ms": tree_ms, "algorithmic_bytes_per_launch": by,
                      "note": "latency-bound: one wavefront per game walks its tree with dependent loads; see DESIGN.md"}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this workload (WRITE_SIZE + 2 x FETCH_SIZE,
+        # separate passes; profiles/r01_selfplay64_pmc_hbm.json) - PMC counters cannot be read from inside the bench
+        pmc = _pmc_traffic("profiles/r01_selfplay64_pmc_hbm.json")
+        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward_kernel<2,false>")):
+            if key in pmc and args.games == 64 and args.nodes == 400 and args.model == "small":
+                r_["traffic"] = pmc[key]
+                r_["traffic_source"] = "profiles/r01_selfplay64_pmc_hbm.json (rocprofv3 --pmc, same workload)"
         roof = roof_net if dominant.startswith("RISEv3") else roof_tree
         extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
@@ -235,8 +256,9 @@ def main():
                                                       "net_TFLOPs": r.eval_rows / it256 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
             pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
             extra["plane_encode_64k"] = pl
+            enc = _pmc_traffic("profiles/r01_bench_pmc_hbm.json").get("void encode_planes_kernel<0>")
             extra["rooflines"].append({"bound": "hbm", "achieved": pl["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": pl["hbm_frac"], "traffic": None, "kernel": "encode_planes_kernel<f16>",
+                                       "frac": pl["hbm_frac"], "traffic": enc, "kernel": "encode_planes_kernel<f16>",
                                        "kernel_ms": pl["kernel_ms"], "algorithmic_bytes_per_launch": pl["algorithmic_bytes_per_launch"]})
             if rank == 0 and not args.no_cpu_baseline:
                 extra["plane_encode_64k"]["cpu_baseline"] = cpu_planes_baseline(boards, out, 5.0)
