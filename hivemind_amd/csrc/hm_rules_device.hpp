@@ -345,12 +345,6 @@ __device__ __attribute__((noinline)) bool waiting_board_mate_scan(LdsRulesTab tl
             }
         }
         TRACE_EV(12, r, (persists ? 1 : 0) | (drawAfter ? 2 : 0));
-#ifdef HM_DBG_WBM
-        if (!persists && (int)blockIdx.x == g_traceGame && threadIdx.x == 0) {
-            const unsigned k_ = g_traceCount++;
-            if (k_ < 4096u) g_trace[k_] = ((unsigned long long)r << 48) | ((unsigned long long)nr << 40) | ((unsigned long long)nm << 32) | (unsigned long long)reply | (drawAfter ? 1ULL << 31 : 0ULL);
-        }
-#endif
         if (!persists) return false;
     }
     return true;

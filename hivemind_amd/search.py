@@ -43,6 +43,9 @@ _SIGS = {
     "hm_sp_raw_policy": (_i, [_vp] * 8),
     "hm_sp_action_terminal": (_i, [_vp, _vp, _vp, _vp]),
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
+    "hm_sp_profile": (_i, [_vp, _i]),
+    "hm_sp_trace_select": (_i, [_i]),
+    "hm_sp_trace": (_i, [_vp, _i]),
 }
 for _n, (_r, _a) in _SIGS.items():
     _f = getattr(lib, _n)

@@ -218,6 +218,15 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
  * history-free boards (d_out: n*8 ints, d_keys: n*4 u64: hash_key(adv=0), hash_key(adv=1), repetition keys). */
 int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
 
+/* Diagnostics of the tree kernels (no reference counterpart; all no-ops / zeros in the product build).
+ * hm_sp_profile: cycle accounting of game slot 0, out64[0..31] cycles and out64[32..63] call counts per probe
+ * (library built with -DHM_SEARCH_PROF; tools/profile_search.py).  hm_sp_trace_select / hm_sp_trace: per-attempt
+ * event log of collect_batch for one game slot, encoded as oracle Search::ctxTrace (library built with
+ * -DHM_SEARCH_TRACE; tools/dbg_ctx.py).  hm_sp_trace returns the number of events logged. */
+int hm_sp_profile(unsigned long long* out64, int reset);
+int hm_sp_trace_select(int game);
+int hm_sp_trace(unsigned long long* out, int cap);
+
 /* ================================================================== */
 /* RISEv3 forward as one kernel launch (evaluator hot op; replaces the  */
 /* TensorRT FP16 plan of nn/engine.cc:290-401,577-650).  desc = packed  */

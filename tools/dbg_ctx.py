@@ -1,6 +1,15 @@
 """Compare the collect_batch event logs (oracle Search::ctxTrace vs GPU -DHM_SEARCH_TRACE build) of one root."""
-import ctypes as C, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRACE_LIB = os.path.join(ROOT, "hivemind_amd", "csrc", "libhivemind_amd_trace.so")
+if "--build" in sys.argv:      # python tools/dbg_ctx.py --build   (here), then on the GPU: python tools/dbg_ctx.py [nodes] [game]
+    src = [os.path.join(ROOT, "hivemind_amd", "csrc", f) for f in ("hm_kernels.hip", "hm_search.hip", "hm_selfplay.hip", "hm_net.hip")]
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared",
+                           "-DHM_SEARCH_TRACE", "-I", os.path.join(ROOT, "include"), *src, "-o", TRACE_LIB])
+    print("built", TRACE_LIB); sys.exit(0)
+os.environ.setdefault("HIVEMIND_AMD_LIB", TRACE_LIB)
+import numpy as np, torch
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hivemind_amd as hm, oracle_py as O
 from hivemind_amd import _lib
 from test_gpu_search import _hash_eval_gpu, _roots

@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import hivemind_amd as hm, oracle_py as O
 from test_gpu_search import _hash_eval_gpu, _roots
 hm.init(0)
