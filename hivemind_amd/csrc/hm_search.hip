@@ -132,6 +132,8 @@ struct Pools {
     TrajEnt* traj;        // [nGames][2][BATCH][MAX_TRAJ]
     u64* hist;            // [nGames][2][HIST_CAP]
     float* noise;         // [nGames][2][NOISE_CAP]
+    u32* leafMoves;       // [nGames][2 batches][BATCH rows][2 boards][HM_MAX_MOVES]: filtered legal lists of the network leaves
+    int* leafCounts;      // [nGames][2][BATCH][2]
     const float* cpuctTab;   // [MAX_VISITS_TAB]
     const int* pwRoot;       // [MAX_VISITS_TAB]
     const int* pwNode;
@@ -198,6 +200,8 @@ struct G {               // per-wave view of one game's pools
     TrajEnt* traj;
     u64* hist[2];
     float* noise[2];
+    u32* leafMoves;          // this game's [2][BATCH][2][HM_MAX_MOVES]
+    int* leafCounts;         // [2][BATCH][2]
     const Params* prm;
     const Pools* pl;
 };
@@ -766,6 +770,8 @@ struct WaveLds {
     };
     u64 board[BATCH][26];    // hm_board images of this batch's network leaves, handed to the plane-writer wave
     int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
+    int postBuf;             // which of the two batches (0/1) the posted leaves belong to
+    u32 helperLists[2][HM_MAX_MOVES];   // wave 1: legal lists of the leaf being served
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
     u64 unavail[8];
@@ -785,6 +791,8 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.hist[1] = pl.hist + ((size_t)g * 2 + 1) * HIST_CAP;
     s.noise[0] = pl.noise + ((size_t)g * 2 + 0) * NOISE_CAP;
     s.noise[1] = pl.noise + ((size_t)g * 2 + 1) * NOISE_CAP;
+    s.leafMoves = pl.leafMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES;
+    s.leafCounts = pl.leafCounts + (size_t)g * 2 * BATCH * 2;
     s.prm = &prm; s.pl = &pl;
     return s;
 }
@@ -792,7 +800,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
 // process of one context list (searchthread.cc:444-639).  outs == nullptr for terminal-only batches.
 struct NetOut { const uint16_t *value, *piA, *piB, *wdl, *ml; };
 
-__device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
+__device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int buf, int row, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
     const int lane = threadIdx.x & 63;
     P bd[2];
     load_pos(bd[0], &ctx.pos[0]);
@@ -800,25 +808,17 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     const int team = ctx.team;
     const bool leafAdv = team == rootTeam ? rootAdv : !rootAdv;
     const bool aOn = (int)bd[0].stm == team, bOn = (int)bd[1].stm == (team ^ 1);
-    // legal moves of the on-turn boards: lane 0 -> A, lane 1 -> B (same code path, no divergence)
+    // legal moves of the on-turn boards (R/B under-promotions already erased, utils.h:169-182): generated by the
+    // plane-writer wave of k_collect while the traversal went on, fetched here
     PROF_T(te1);
-    int cntMine = 0;
-    if (lane < 2) {
-        const bool on = lane == 0 ? aOn : bOn;
-        if (on) {
-            u32* list = L.lists[lane];
-            int n = gen_legal(rt.att, pick_pos(bd, lane), list);
-            int k = 0;
-            for (int i = 0; i < n; ++i) {                      // erase R/B under-promotions (utils.h:169-182), order kept
-                const u32 m = list[i];
-                const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
-                if (!bad) list[k++] = m;
-            }
-            cntMine = k;
-        }
-    }
     int nReal[2];
-    nReal[0] = ulane(cntMine, 0); nReal[1] = ulane(cntMine, 1);
+    {
+        const int* cnt = s.leafCounts + ((size_t)buf * BATCH + row) * 2;
+        nReal[0] = cnt[0]; nReal[1] = cnt[1];
+        const u32* src = s.leafMoves + ((size_t)buf * BATCH + row) * 2 * HM_MAX_MOVES;
+        for (int b = 0; b < 2; ++b)
+            for (int i = lane; i < nReal[b]; i += 64) L.lists[b][i] = src[(size_t)b * HM_MAX_MOVES + i];
+    }
     __builtin_amdgcn_wave_barrier();
     PROF_ADD(21, te1);
     PROF_T(te2);
@@ -983,10 +983,11 @@ __device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int b
     const Ctx& ctx = s.ctx[buf * BATCH + i];
     if (ctx.terminal) return;
     if (s.nodes[ctx.leaf].type != T_UNSOLVED) return;
-    const int row = rowBase + ctx_row(s, buf, i);
+    const int slot = ctx_row(s, buf, i);               // index of this leaf among the batch's network leaves
+    const int row = rowBase + slot;
     if (ctx.leafHash != 0) s.nodes[ctx.leaf].hash = ctx.leafHash;
     if (!(s.nodes[ctx.leaf].flags & F_EXPANDED))
-        expand_leaf(s, rt, L, ctx, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
+        expand_leaf(s, rt, L, ctx, buf, slot, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
 }
 __device__ inline void backup_batch(G& s, int buf, const NetOut* out, int rowBase) {
     const int n = s.g->ctxCount[buf];
@@ -1122,7 +1123,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
                 PROF_ADD(25, tp);
                 PROF_T(tw);
                 // the planes are written by the second wave of the block while this one goes on selecting
-                if (lane == 0) __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) { L.postBuf = buf; __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
                 (void)planesOut;
                 PROF_ADD(26, tw);
                 PROF_ADD(7, tp);
@@ -1232,6 +1233,40 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
     PROF_ADD(12, te);
 }
 
+// Legal move lists of network leaf `slot` (both boards, lane 0 -> A, lane 1 -> B, R/B under-promotions erased as
+// utils.h:169-182) from its hm_board image: the expansion in k_process reads them instead of generating.
+__device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, WaveLds& L, int g, int slot) {
+    const int lane = threadIdx.x & 63;
+    const hm_board* hb = reinterpret_cast<const hm_board*>(L.board[slot]);
+    const int buf = L.postBuf;
+    int cnt = 0;
+    if (lane < 2) {
+        P p;
+        load_pos(p, &hb->pos[lane]);
+        const int team = hb->team;
+        const bool on = lane == 0 ? (int)p.stm == team : (int)p.stm == (team ^ 1);
+        if (on) {
+            u32* list = L.helperLists[lane];
+            const int n = gen_legal(rt.att, p, list);
+            int k = 0;
+            for (int i = 0; i < n; ++i) {
+                const u32 m = list[i];
+                const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
+                if (!bad) list[k++] = m;
+            }
+            cnt = k;
+        }
+    }
+    const int nA = ulane(cnt, 0), nB = ulane(cnt, 1);
+    __builtin_amdgcn_wave_barrier();
+    const size_t base = (((size_t)g * 2 + buf) * BATCH + slot) * 2;
+    u32* dst = pl.leafMoves + base * HM_MAX_MOVES;
+    for (int i = lane; i < nA; i += 64) dst[i] = L.helperLists[0][i];
+    for (int i = lane; i < nB; i += 64) dst[HM_MAX_MOVES + i] = L.helperLists[1][i];
+    if (lane == 0) { pl.leafCounts[base] = nA; pl.leafCounts[base + 1] = nB; }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
 // posts in LDS into fp16 planes, so the 9.4 KB plane writes overlap the next descent instead of extending it.
 __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
@@ -1263,6 +1298,7 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
                 if (served >= posted) break;
             }
             write_planes_f16(s_rt, L.board[served], reinterpret_cast<uint4*>(dst + (size_t)served * HM_PLANE_VALUES), L.pmask, L.pval);
+            leaf_move_lists(pl, s_rt, L, blockIdx.x, served);
             served++;
         }
     }
@@ -1764,6 +1800,8 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     rc |= dalloc(sp, &pl.traj, G_ * 2 * BATCH * MAX_TRAJ);
     rc |= dalloc(sp, &pl.hist, G_ * 2 * HIST_CAP);
     rc |= dalloc(sp, &pl.noise, G_ * 2 * NOISE_CAP);
+    rc |= dalloc(sp, &pl.leafMoves, G_ * 2 * BATCH * 2 * HM_MAX_MOVES);
+    rc |= dalloc(sp, &pl.leafCounts, G_ * 2 * BATCH * 2);
     if (rc) { hm_sp_destroy(sp); return rc; }
     // cpuct(N) and the PW schedule from the reference's own float expressions (search_params.h:307-317)
     std::vector<float> cp(MAX_VISITS_TAB);
