@@ -94,6 +94,18 @@ def legal_moves(pos: torch.Tensor, stream=None):
     return moves, counts
 
 
+def legal_moves_wave(pos: torch.Tensor, stream=None):
+    """As legal_moves, from the wave-cooperative generator of the search kernels (test hook)."""
+    _require_init()
+    if pos.device.type != "cuda" or pos.dtype != torch.uint8 or pos.shape[-1] != 96 or not pos.is_contiguous():
+        raise HivemindError("pos must be a contiguous uint8 CUDA tensor of shape [n, 96]")
+    n = pos.shape[0]
+    moves = torch.zeros((n, MAX_MOVES), dtype=torch.int32, device=pos.device)
+    counts = torch.empty((n,), dtype=torch.int32, device=pos.device)
+    check(lib.hm_legal_moves_wave(pos.data_ptr(), n, moves.data_ptr(), counts.data_ptr(), _stream_ptr(stream)))
+    return moves, counts
+
+
 def count_moves(pos: torch.Tensor, stream=None) -> torch.Tensor:
     _require_init()
     n = pos.shape[0]

@@ -48,6 +48,7 @@ _SIGS = {
     "hm_policy_index": (_i, [C.c_uint32, _i]),
     "hm_encode_planes": (_i, [_vp, _sz, _i, _vp, _vp]),
     "hm_legal_moves": (_i, [_vp, _sz, _vp, _vp, _vp]),
+    "hm_legal_moves_wave": (_i, [_vp, _sz, _vp, _vp, _vp]),
     "hm_count_moves": (_i, [_vp, _sz, _vp, _vp]),
     "hm_make_moves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "hm_perft": (_i, [_vp, _i, _i, _i, _u64p, C.POINTER(C.c_double)]),

@@ -390,6 +390,175 @@ __device__ __forceinline__ int gen_legal_to(const AttackTab& t, const P& p, u32*
     return gen_legal_glb((LdsAttackTab)&t, p, out);
 }
 
+// Wave-cooperative generate<LEGAL>: all 64 lanes of a wave call this with the SAME position; the list (identical
+// to gen_legal's, order included) lands in `out` (LDS).  Each emission group of the reference order is a
+// bitboard whose set bits map to list slots by rank: pawn / drop / king groups take one lane per target square,
+// the piece groups one lane per from-square with a wave prefix sum over the per-piece target counts; the
+// swap-with-last removal of the illegal entries is replayed hole by hole with ballots.
+__device__ __forceinline__ int gen_legal_wave_body(const AttackTab& t, const P& p, u32* out) {
+    const int lane = threadIdx.x & 63;
+    Analysis an;
+    analyse(t, p, an);
+    const int us = p.stm, them = us ^ 1, k = an.ksq;
+    const u64 occ = occ_of(p), ours = bc_of(p, us), theirs = bc_of(p, them);
+    const bool evasion = an.checkers != 0;
+    const u64 lbit = bit(lane), below = lbit - 1;
+    int n = 0;
+    auto pin_ok = [&](int from, int to) -> u32 {
+        return (!(an.pinned & bit(from)) || (line_through(t, k, from) & bit(to))) ? 0u : ILLEGAL_FLAG;
+    };
+    // one list slot (or `mult` consecutive slots) per set bit of B, in LSB order; this lane serves bit `lane`
+    auto slot_of = [&](u64 B, int mult) -> int { return (B & lbit) ? n + mult * popc(B & below) : -1; };
+    if (!evasion || !(an.checkers & (an.checkers - 1))) {
+        const u64 target = evasion ? between_incl(t, k, lsb(an.checkers)) : ~ours;
+        {   // ---- pawns
+            const int up = us == 0 ? 8 : -8;
+            const u64 r7 = us == 0 ? (RANK_1 << 48) : (RANK_1 << 8);
+            const u64 r3 = us == 0 ? (RANK_1 << 16) : (RANK_1 << 40);
+            const u64 empty = ~occ;
+            const u64 enemies = evasion ? an.checkers : theirs;
+            const u64 pawns = p.bt[0] & ours;
+            const u64 on7 = pawns & r7, not7 = pawns & ~r7;
+            const int dUR = us == 0 ? 9 : -9, dUL = us == 0 ? 7 : -7;
+            auto shUp = [&](u64 b) { return us == 0 ? b << 8 : b >> 8; };
+            auto shUR = [&](u64 b) { return us == 0 ? (b & ~FILE_H) << 9 : (b & ~FILE_A) >> 9; };
+            auto shUL = [&](u64 b) { return us == 0 ? (b & ~FILE_A) << 7 : (b & ~FILE_H) >> 7; };
+            u64 b1 = shUp(not7) & empty;
+            u64 b2 = shUp(b1 & r3) & empty;
+            if (evasion) { b1 &= target; b2 &= target; }
+            int sl = slot_of(b1, 1);
+            if (sl >= 0) out[sl] = mk(lane - up, lane) | pin_ok(lane - up, lane);
+            n += popc(b1);
+            sl = slot_of(b2, 1);
+            if (sl >= 0) out[sl] = mk(lane - 2 * up, lane) | pin_ok(lane - 2 * up, lane);
+            n += popc(b2);
+            if (on7) {
+                u64 p1 = shUR(on7) & enemies, p2 = shUL(on7) & enemies, p3 = shUp(on7) & empty;
+                if (evasion) p3 &= target;
+                const u64 pb[3] = {p1, p2, p3};
+                const int pd[3] = {dUR, dUL, up};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    sl = slot_of(pb[q], 4);
+                    if (sl >= 0) {
+                        const int from = lane - pd[q];
+                        const u32 f = pin_ok(from, lane);
+#pragma unroll
+                        for (int pt = 5; pt >= 2; --pt) out[sl + (5 - pt)] = mk_t(HM_MT_PROMOTION, from, lane, pt) | f;
+                    }
+                    n += 4 * popc(pb[q]);
+                }
+            }
+            const u64 c1 = shUR(not7) & enemies, c2 = shUL(not7) & enemies;
+            sl = slot_of(c1, 1);
+            if (sl >= 0) out[sl] = mk(lane - dUR, lane) | pin_ok(lane - dUR, lane);
+            n += popc(c1);
+            sl = slot_of(c2, 1);
+            if (sl >= 0) out[sl] = mk(lane - dUL, lane) | pin_ok(lane - dUL, lane);
+            n += popc(c2);
+            if (p.ep < 64 && !(evasion && (target & bit((int)p.ep + up)))) {
+                const u64 e = not7 & t.pawn[them][p.ep];         // from-squares, LSB order
+                sl = slot_of(e, 1);
+                if (sl >= 0) out[sl] = mk_t(HM_MT_EN_PASSANT, lane, p.ep, 0) | (ep_legal(t, p, k, lane, p.ep) ? 0u : ILLEGAL_FLAG);
+                n += popc(e);
+            }
+        }
+        // ---- knights, bishops, rooks, queens: lane = from-square, slots by wave prefix sum of the target counts
+#pragma unroll
+        for (int ty = 1; ty <= 4; ++ty) {
+            const u64 bb = p.bt[ty] & ours;
+            if (!bb) continue;                                      // uniform
+            u64 tg = 0;
+            if (bb & lbit) {
+                tg = ty == 1 ? t.knight[lane]
+                   : ty == 2 ? bishop_att(t, lane, occ)
+                   : ty == 3 ? rook_att(lane, occ)
+                             : (rook_att(lane, occ) | bishop_att(t, lane, occ));
+                tg &= target;
+            }
+            const int cnt = popc(tg);
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            int sl2 = n + incl - cnt;
+            const u32 kf = (ty == 1 && (an.pinned & lbit)) ? ILLEGAL_FLAG : 0u;   // a pinned knight never moves on its line
+            while (tg) {
+                const int to = pop_lsb(tg);
+                out[sl2++] = mk(lane, to) | (ty == 1 ? kf : pin_ok(lane, to));
+            }
+            n += ulane(incl, 63);
+        }
+        {   // ---- drops (virtual drops for empty pockets in evasions are emitted flagged, as the reference does)
+            const u64 b0 = target & ~occ;
+            const int ek = lsb(p.bt[5] & theirs);
+#pragma unroll
+            for (int pt = 1; pt <= 5; ++pt) {
+                u64 b = pt == 1 ? (b0 & ~(RANK_1 | RANK_8)) : b0;
+                u32 fl = 0;
+                if (hand_get(p, us, pt) == 0) {
+                    if (!evasion) continue;                         // uniform
+                    const u64 cs = pt == 1 ? t.pawn[them][ek]
+                                 : pt == 2 ? t.knight[ek]
+                                 : pt == 3 ? bishop_att(t, ek, occ)
+                                 : pt == 4 ? rook_att(ek, occ)
+                                           : (rook_att(ek, occ) | bishop_att(t, ek, occ));
+                    b &= cs;
+                    fl = ILLEGAL_FLAG;
+                }
+                const int sl = slot_of(b, 1);
+                if (sl >= 0) out[sl] = mk_drop(lane, pt) | fl;
+                n += popc(b);
+            }
+        }
+    }
+    {   // ---- king
+        const u64 b = t.king[k] & ~ours;
+        const int sl = slot_of(b, 1);
+        if (sl >= 0) out[sl] = mk(k, lane) | ((an.danger & lbit) ? ILLEGAL_FLAG : 0u);
+        n += popc(b);
+        if (!evasion) {
+            const u32 rights = us == 0 ? (p.castling & 3) : ((p.castling >> 2) & 3);
+            const int base = us == 0 ? 0 : 56;
+            if ((rights & 1) && !(occ & (bit(base + 5) | bit(base + 6))))
+                out[n++] = mk_t(HM_MT_CASTLING, k, base + 7, 0) | ((an.danger & (bit(base + 5) | bit(base + 6))) ? ILLEGAL_FLAG : 0u);
+            if ((rights & 2) && !(occ & (bit(base + 1) | bit(base + 2) | bit(base + 3))))
+                out[n++] = mk_t(HM_MT_CASTLING, k, base, 0) | ((an.danger & (bit(base + 2) | bit(base + 3))) ? ILLEGAL_FLAG : 0u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- generate<LEGAL> compaction (movegen.cpp:449-453): every illegal entry is overwritten by the last element;
+    // replayed as "first illegal at or after cur" (ballot) <- "last legal before n" (illegal tail entries drop out)
+    int cur = 0;
+    while (cur < n) {
+        int hole = -1;
+        for (int base = cur & ~63; base < n && hole < 0; base += 64) {
+            const int i = base + lane;
+            const bool bad = i >= cur && i < n && (out[i] & ILLEGAL_FLAG);
+            const u64 m = __ballot(bad);
+            if (m) hole = base + __builtin_ctzll(m);
+        }
+        if (hole < 0) break;
+        --n;
+        while (n > hole && (out[n] & ILLEGAL_FLAG)) --n;            // uniform LDS reads
+        if (n > hole) { const u32 mv = out[n]; __builtin_amdgcn_wave_barrier(); out[hole] = mv; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        cur = hole + 1;
+    }
+    return n;
+}
+
+// (a real call, like gen_legal: position by value, tables and list as LDS pointers)
+__device__ __attribute__((noinline)) int gen_legal_wave_lds(LdsAttackTab t, const P p, LdsList out) {
+    return gen_legal_wave_body(*(const AttackTab*)t, p, (u32*)out);
+}
+__device__ __forceinline__ int gen_legal_wave(const AttackTab& t, const P& p, u32* out) {
+    return gen_legal_wave_lds((LdsAttackTab)&t, p, (LdsList)out);
+}
+
 // Legal move COUNT only (bulk counting at perft leaves): same set as gen_legal, no list.
 __device__ inline int count_legal(const AttackTab& t, const P& p) {
     Analysis an;

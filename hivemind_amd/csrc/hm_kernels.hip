@@ -169,6 +169,25 @@ __global__ __launch_bounds__(256) void legal_moves_kernel(const DeviceTables* __
     }
 }
 
+// Test hook for gen_legal_wave (the wave-cooperative generator of the search kernels): one wave per position.
+__global__ __launch_bounds__(64) void legal_moves_wave_kernel(const DeviceTables* __restrict__ tab,
+                                                              const hm_pos* __restrict__ pos, size_t n,
+                                                              u32* __restrict__ moves, u32* __restrict__ counts) {
+    __shared__ AttackTab s_att;
+    __shared__ u32 s_list[HM_MAX_MOVES];
+    stage_table(&s_att, &tab->att);
+    __syncthreads();
+    for (size_t i = blockIdx.x; i < n; i += gridDim.x) {
+        P p;
+        load_pos(p, pos + i);
+        const int cnt = gen_legal_wave(s_att, p, s_list);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 64) moves[i * HM_MAX_MOVES + k] = s_list[k];
+        if (threadIdx.x == 0) counts[i] = (u32)cnt;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void count_moves_kernel(const DeviceTables* __restrict__ tab,
                                                           const hm_pos* __restrict__ pos, size_t n,
                                                           u32* __restrict__ counts) {
@@ -461,6 +480,16 @@ int hm_legal_moves(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_
     if (n == 0) return 0;
     if (!d_pos || !d_moves || !d_counts) return fail(HM_ERR_INVALID, "null device pointer");
     hipLaunchKernelGGL(legal_moves_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       g.d_tab, d_pos, n, d_moves, d_counts);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int hm_legal_moves_wave(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_counts, void* stream) {
+    if (int rc = ensure_ready()) return rc;
+    if (n == 0) return 0;
+    if (!d_pos || !d_moves || !d_counts) return fail(HM_ERR_INVALID, "null device pointer");
+    hipLaunchKernelGGL(legal_moves_wave_kernel, dim3((unsigned)std::min<size_t>(n, 8192)), dim3(64), 0, static_cast<hipStream_t>(stream),
                        g.d_tab, d_pos, n, d_moves, d_counts);
     HIPCHK(hipGetLastError());
     return 0;

@@ -248,8 +248,7 @@ __device__ inline int immediate_mates_on_board(const RulesTab& t, const JBoard& 
     u32* list = scratch;
     int n = 0;
     const P src = pick_pos(j.bd, b), other = pick_pos(j.bd, 1 - b);
-    if (lane == 0) n = gen_legal(t.att, src, list);
-    n = ulane(n, 0);
+    n = gen_legal_wave(t.att, src, list);              // wave-uniform call
     __builtin_amdgcn_wave_barrier();
     TRACE_EV(13, n, b);
     int k = 0;
@@ -300,7 +299,7 @@ __device__ __attribute__((noinline)) bool waiting_board_mate_scan(LdsRulesTab tl
     if (!nm) return false;
     u32* replies = scratch + HM_MAX_MOVES;
     const P actP = pick_pos(j.bd, active), waitP = pick_pos(j.bd, waiting);
-    int nr = gen_legal(t.att, actP, replies);
+    int nr = gen_legal_wave(t.att, actP, replies);
     if (adv) replies[nr++] = 0;
     TRACE_EV(11, nr, adv);
     if (!nr) return false;
@@ -332,7 +331,7 @@ __device__ __attribute__((noinline)) bool waiting_board_mate_scan(LdsRulesTab tl
             for (int i = 0; i < nm && !persists; ++i) {
                 const u32 mm = mating[i];
                 // is_legal_move(waiting, mm)
-                const int nl = gen_legal(t.att, nw, tmp);
+                const int nl = gen_legal_wave(t.att, nw, tmp);
                 bool legal = false;
                 for (int q = 0; q < nl; ++q) legal |= tmp[q] == mm;
                 if (!legal) continue;

@@ -771,7 +771,7 @@ struct WaveLds {
     u64 board[BATCH][26];    // hm_board images of this batch's network leaves, handed to the plane-writer wave
     int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
     int postBuf;             // which of the two batches (0/1) the posted leaves belong to
-    u32 helperLists[2][HM_MAX_MOVES];   // wave 1: legal lists of the leaf being served
+    u32 helperLists[1][HM_MAX_MOVES];   // wave 1: legal list of the leaf board being served
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
     u64 unavail[8];
@@ -1238,33 +1238,29 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
 __device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, WaveLds& L, int g, int slot) {
     const int lane = threadIdx.x & 63;
     const hm_board* hb = reinterpret_cast<const hm_board*>(L.board[slot]);
-    const int buf = L.postBuf;
-    int cnt = 0;
-    if (lane < 2) {
-        P p;
-        load_pos(p, &hb->pos[lane]);
-        const int team = hb->team;
-        const bool on = lane == 0 ? (int)p.stm == team : (int)p.stm == (team ^ 1);
-        if (on) {
-            u32* list = L.helperLists[lane];
-            const int n = gen_legal(rt.att, p, list);
-            int k = 0;
-            for (int i = 0; i < n; ++i) {
-                const u32 m = list[i];
-                const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
-                if (!bad) list[k++] = m;
-            }
-            cnt = k;
-        }
-    }
-    const int nA = ulane(cnt, 0), nB = ulane(cnt, 1);
-    __builtin_amdgcn_wave_barrier();
+    const int buf = L.postBuf, team = hb->team;
     const size_t base = (((size_t)g * 2 + buf) * BATCH + slot) * 2;
-    u32* dst = pl.leafMoves + base * HM_MAX_MOVES;
-    for (int i = lane; i < nA; i += 64) dst[i] = L.helperLists[0][i];
-    for (int i = lane; i < nB; i += 64) dst[HM_MAX_MOVES + i] = L.helperLists[1][i];
-    if (lane == 0) { pl.leafCounts[base] = nA; pl.leafCounts[base + 1] = nB; }
-    __builtin_amdgcn_wave_barrier();
+    for (int b = 0; b < 2; ++b) {
+        P p;
+        load_pos(p, &hb->pos[b]);
+        const bool on = b == 0 ? (int)p.stm == team : (int)p.stm == (team ^ 1);
+        int kept = 0;
+        if (on) {
+            u32* list = L.helperLists[0];
+            const int n = gen_legal_wave(rt.att, p, list);          // wave-cooperative, reference list order
+            u32* dst = pl.leafMoves + (base + b) * HM_MAX_MOVES;
+            for (int c0 = 0; c0 < n; c0 += 64) {                    // order-preserving erase of the R/B under-promotions
+                const int i = c0 + lane;
+                const u32 m = i < n ? list[i] : 0u;
+                const bool keep = i < n && !((m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP));
+                const u64 km = __ballot(keep);
+                if (keep) dst[kept + __popcll(km & ((1ULL << lane) - 1ULL))] = m;
+                kept += __popcll(km);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) pl.leafCounts[base + b] = kept;
+    }
 }
 
 // Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
@@ -1362,9 +1358,8 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         u32* ord = L.lists[4];           // low 16: A order, high 16: B order (stable_partition by gives_check)
         u32* hits = L.lists[5];
         int nA = 0, nB = 0;
-        if (lane == 0 && aOn) nA = gen_legal(rt.att, p.jb.bd[0], la);
-        if (lane == 1 && bOn) nB = gen_legal(rt.att, p.jb.bd[1], lb);
-        nA = ulane(nA, 0); nB = ulane(nB, 1);
+        if (aOn) nA = gen_legal_wave(rt.att, p.jb.bd[0], la);
+        if (bOn) nB = gen_legal_wave(rt.att, p.jb.bd[1], lb);
         rootHashOut[2 * g + 1] = (u64)(u32)(nA + 1) | ((u64)(u32)(nB + 1) << 32);
         __builtin_amdgcn_wave_barrier();
         const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;

@@ -127,6 +127,8 @@ int hm_legal_moves(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_
 
 /* Legal move COUNT only (MoveList<LEGAL>::size(), used by is_checkmate board.cc:169-208 and
  * the perft depth-1 shortcut benchmark.cc:66). d_counts: n. */
+/* Test hook: the same lists from the wave-cooperative generator the search kernels use (one wavefront per position). */
+int hm_legal_moves_wave(const hm_pos* d_pos, size_t n, hm_move* d_moves, uint32_t* d_counts, void* stream);
 int hm_count_moves(const hm_pos* d_pos, size_t n, uint32_t* d_counts, void* stream);
 
 /* Batched joint make: Board::make_moves (board.cc:316-341) applied to

@@ -86,6 +86,21 @@ def test_legal_moves_match_oracle_random(hm):
     assert np.array_equal(cc, cnt)
 
 
+def test_wave_generator_equals_thread_generator(hm):
+    """gen_legal_wave (wave-cooperative, used inside the search kernels) against gen_legal (one lane per position,
+    itself pinned by the reference fixture above): identical lists, order included, on 200k positions."""
+    import torch
+    boards = np.concatenate([O.random_positions(7, 60000, 400), O.random_positions(8, 40000, 60)])
+    pos = hm.to_device(np.ascontiguousarray(boards["pos"].reshape(-1)))
+    a, ca = hm.legal_moves(pos)
+    b, cb = hm.legal_moves_wave(pos)
+    torch.cuda.synchronize()
+    assert torch.equal(ca, cb), int((ca != cb).nonzero()[0])
+    idx = torch.arange(a.shape[1], device=a.device)[None, :] < ca[:, None]
+    bad = ((a != b) & idx).any(dim=1)
+    assert not bool(bad.any()), int(bad.nonzero()[0])
+
+
 def test_make_moves_match_oracle(hm):
     import torch
     boards = O.random_positions(5, 3000, 200)
