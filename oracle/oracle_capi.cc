@@ -241,3 +241,7 @@ double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, i
 }
 
 }  // extern "C"
+
+#if __has_include("search.hpp")
+#include "oracle_lab.cc"
+#endif

@@ -163,6 +163,7 @@ public:
         if (heap.empty()) { push(1, 0); push(0, 1); }
     }
     bool hasNext() const { return !heap.empty(); }
+    Candidate peekNext() const { return heap.empty() ? Candidate() : heap.top(); }   // :305-310
     Candidate getNext() {   // :312-328
         if (heap.empty()) return Candidate();
         Candidate best = heap.top();
@@ -230,23 +231,82 @@ struct Node {
         const float coef = depth == 0 ? c.rootPwCoefficient : c.pwCoefficient;
         return gen.hasNext() && expandedCount < get_allowed_children(visits + virtualVisitSum, coef, c.pwExponent);
     }
-    // expand_next_joint_child with existingNode == nullptr, reserveForSelection == true (:199-262)
-    std::shared_ptr<Node> expand_next_joint_child(Candidate& outAction, int* outIdx, bool* outReserved, int& nodeCounter) {
-        *outReserved = false;
+    // expand_next_joint_child (:199-262): existingNode = a transposition-table node to reuse (edge seeded with one
+    // pseudo-visit and Q = -existing.Q()), reserveForSelection = take the evaluation reservation and one virtual loss
+    std::shared_ptr<Node> expand_next_joint_child(std::shared_ptr<Node> existingNode, uint64_t positionHash, Candidate& outAction,
+                                                  int* outIdx, bool reserveForSelection, bool* outReserved, int& nodeCounter) {
+        if (outReserved) *outReserved = false;
         if (!gen.hasNext()) return nullptr;
         Candidate cand = gen.getNext();
         outAction = cand;
-        auto child = std::make_shared<Node>(team ^ 1, 0);
-        child->id = nodeCounter++;
-        child->depth = depth + 1;
-        if (!child->try_reserve()) return nullptr;
-        *outReserved = true;
-        childValueSum.push_back(Q_INIT); childPriors.push_back(cand.jointPrior);
-        childVisits.push_back(0); virtualLoss.push_back(1); virtualVisitSum++;
-        children.push_back(child); qValues.push_back(Q_INIT);
+        std::shared_ptr<Node> child;
+        float childQ;
+        if (existingNode) { child = existingNode; childQ = -existingNode->Q(); }
+        else {
+            child = std::make_shared<Node>(team ^ 1, positionHash);
+            child->id = nodeCounter++;
+            child->depth = depth + 1;
+            childQ = Q_INIT;
+        }
+        if (reserveForSelection) {
+            if (!child->try_reserve()) return nullptr;
+            if (outReserved) *outReserved = true;
+        }
+        childValueSum.push_back(childQ); childPriors.push_back(cand.jointPrior);
+        childVisits.push_back(existingNode ? 1 : 0);
+        virtualLoss.push_back(reserveForSelection ? 1 : 0);
+        if (reserveForSelection) virtualVisitSum++;
+        children.push_back(child); qValues.push_back(childQ);
         expandedCount++;
-        *outIdx = expandedCount - 1;
+        if (outIdx) *outIdx = expandedCount - 1;
         return child;
+    }
+    void apply_virtual_loss(int i, int amount = 1) { if (i >= 0 && (size_t)i < virtualLoss.size()) { virtualLoss[i] += amount; virtualVisitSum += amount; } }    // :417-423
+    void remove_virtual_loss(int i, int amount = 1) { if (i >= 0 && (size_t)i < virtualLoss.size()) { virtualLoss[i] -= amount; virtualVisitSum -= amount; } }   // :425-431
+    void set_value(float v) { valueSum = v; }                                                                    // :403-406
+    float get_child_q(int i) const { return i >= 0 && (size_t)i < qValues.size() ? qValues[i] : 0.0f; }           // :638-644
+    void replace_child(int i, const std::shared_ptr<Node>& c) { if (i >= 0 && (size_t)i < children.size()) children[i] = c; }   // :373-378
+
+    // get_best_move_idx_with_q_weight (:656-754): solver-aware final move rule with Q-veto and Q-weighting
+    int get_best_move_idx_with_q_weight(float qVetoDelta, float qValueWeight) const {
+        if (childVisits.empty() || qValues.empty()) return -1;
+        if (nodeType == NodeType::WIN) {
+            int bestIdx = -1, shortest = INT32_MAX;
+            for (size_t i = 0; i < childNodeTypes.size(); ++i)
+                if (childNodeTypes[i] == NodeType::LOSS && children[i] && children[i]->endInPly < shortest) { shortest = children[i]->endInPly; bestIdx = (int)i; }
+            if (bestIdx >= 0) return bestIdx;
+        }
+        if (nodeType == NodeType::LOSS) {
+            int bestIdx = 0, longest = 0;
+            for (size_t i = 0; i < children.size(); ++i)
+                if (children[i] && children[i]->endInPly > longest) { longest = children[i]->endInPly; bestIdx = (int)i; }
+            return bestIdx;
+        }
+        const bool hasNonLosing = std::any_of(children.begin(), children.end(), [](const std::shared_ptr<Node>& c) { return c && c->nodeType != NodeType::WIN; });
+        auto eligible = [&](size_t i) { return !hasNonLosing || !children[i] || children[i]->nodeType != NodeType::WIN; };
+        size_t first = 0;
+        while (first < childVisits.size() && !eligible(first)) ++first;
+        if (first == childVisits.size()) return -1;
+        int bestVisitIdx = (int)first, maxVisits = childVisits[first], secondVisitIdx = -1;
+        for (size_t i = first + 1; i < childVisits.size(); ++i) {
+            if (!eligible(i)) continue;
+            if (childVisits[i] > maxVisits) { secondVisitIdx = bestVisitIdx; maxVisits = childVisits[i]; bestVisitIdx = (int)i; }
+            else if (secondVisitIdx < 0 || childVisits[i] > childVisits[secondVisitIdx]) secondVisitIdx = (int)i;
+        }
+        int bestQIdx = (int)first;
+        float bestQ = qValues[first];
+        for (size_t i = first + 1; i < qValues.size(); ++i) {
+            if (!eligible(i)) continue;
+            if (qValues[i] > bestQ) { bestQ = qValues[i]; bestQIdx = (int)i; }
+        }
+        if (qVetoDelta > 0.0f && bestQIdx != bestVisitIdx)
+            if (qValues[bestQIdx] > qValues[bestVisitIdx] + qVetoDelta && childVisits[bestQIdx] > 1) return bestQIdx;
+        if (qValueWeight > 0.0f && secondVisitIdx >= 0 && qValues[secondVisitIdx] > qValues[bestVisitIdx]) {
+            const float qDifference = qValues[secondVisitIdx] - qValues[bestVisitIdx];
+            const float adjusted = childVisits[secondVisitIdx] + qDifference * qValueWeight * childVisits[bestVisitIdx];
+            if (adjusted > childVisits[bestVisitIdx]) return secondVisitIdx;
+        }
+        return bestVisitIdx;
     }
     void init_child_node_types() {   // :531-541
         if (childNodeTypes.size() < children.size()) {
@@ -423,7 +483,7 @@ public:
     Evaluator evaluator;
     std::shared_ptr<Node> root;
     std::unordered_map<uint64_t, std::shared_ptr<Node>> tt;
-    int nodesSearched = 0, sameBatchCollisions = 0, reservationCollisions = 0, evalCalls = 0, evalRows = 0, nodeCounter = 0;
+    int nodesSearched = 0, sameBatchCollisions = 0, reservationCollisions = 0, evalCalls = 0, evalRows = 0, nodeCounter = 0, ttHits = 0;
     // optional trace of every evaluated leaf hash, for step-by-step diffing against the GPU engine
     std::vector<uint64_t> evalTrace;
     // optional per-attempt event log of collect_batch: (collect# << 32) | (code << 24) | (path length << 8) | outcome
@@ -533,7 +593,7 @@ public:
         child->hash = h;
         std::shared_ptr<Node> canonical;
         auto it = tt.find(h);
-        if (it != tt.end()) canonical = it->second; else { tt.emplace(h, child); canonical = child; }
+        if (it != tt.end()) { canonical = it->second; ttHits++; } else { tt.emplace(h, child); canonical = child; }   // insertOrGet transposition_table.h:83-103
         const bool isAncestor = std::any_of(trajectory.begin(), trajectory.end(), [&](const TrajectoryEntry& e) { return e.node.get() == canonical.get(); });
         const bool teamMismatch = canonical->team != child->team;
         if (canonical == child || isAncestor || teamMismatch) return {child->isExpanded, nullptr};
@@ -569,7 +629,7 @@ public:
             if (cur->should_expand_new_child(cfg)) {
                 Candidate act;
                 bool childReserved = false;
-                next = cur->expand_next_joint_child(act, &childIdx, &childReserved, nodeCounter);
+                next = cur->expand_next_joint_child(nullptr, 0, act, &childIdx, true, &childReserved, nodeCounter);
                 if (next) {
                     board.make_moves(act.moveA, act.moveB);
                     Canon cr = canonicalize_child(board, cur.get(), childIdx, act, next, childReserved, rootAdv);
@@ -671,9 +731,9 @@ public:
         }
     }
 
-    void try_init_and_expand(Node& leaf, const std::vector<Move>& aA, const std::vector<Move>& aB, const std::vector<float>& pA,
+    bool try_init_and_expand(Node& leaf, const std::vector<Move>& aA, const std::vector<Move>& aB, const std::vector<float>& pA,
                              const std::vector<float>& pB, bool adv, bool aOn, bool bOn, const std::vector<uint8_t>& cA, const std::vector<uint8_t>& cB) {   // node.h:269-342
-        if (leaf.isExpanded) return;
+        if (leaf.isExpanded) return false;
         std::vector<float> rA = pA, rB = pB;
         if (leaf.depth == 0 && cfg.rootDirichletAlpha > 0.0f && cfg.rootDirichletEpsilon > 0.0f) {
             auto noise = [&](std::vector<float>& pri, uint64_t salt) {
@@ -702,7 +762,9 @@ public:
             leaf.children.push_back(child); leaf.qValues.push_back(Q_INIT);
             leaf.expandedCount++;
             leaf.isExpanded = true;
+            return true;
         }
+        return false;
     }
 
     float shape_value(uint16_t valueH, const uint16_t* wdl, uint16_t mlH) {   // searchthread.cc:569-619
