@@ -52,8 +52,7 @@ namespace hms {
 
 constexpr int BATCH = 8;                 // SearchParams::BATCH_SIZE
 constexpr int MAX_TRAJ = 96;             // search path cap (root .. leaf)
-constexpr int HIST_GAME = 1024;          // game history keys per board
-constexpr int HIST_CAP = HIST_GAME + MAX_TRAJ + 8;
+constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown to the run's macro-ply limit, hm_sp_create_ex)
 constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
 constexpr int MAX_VISITS_TAB = 1 << 15;  // cpuct / PW tables
 constexpr int NLISTS = 8;                // LDS scratch move lists per wave
@@ -112,14 +111,16 @@ struct Game {
     int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
     int nodesVisited, edgesScanned;     // traversal traffic counters (roofline accounting)
     int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
+    int live;                           // slot holds a game (set by k_set_games); dead slots are skipped by every kernel
 };
 
 struct Params {          // device-visible configuration + pool geometry
     int nGames, nodeCap, ttCap;        // ttCap power of two
+    int histGame, histCap;             // per-board history keys: game part / game + search path
     u32 arenaCap;                      // 8-byte units
     float cpuctInit, cpuctBase, fpuReduction, drawContempt, wdlWeight, mlDiscount;
     int enableTranspositions, enableDynamicFpu, enableWdl;
-    float eps_unused;
+    float qVetoDelta, qValueWeight;      // SearchParams::Q_VETO_DELTA / Q_VALUE_WEIGHT (search_params.h)
 };
 
 struct Pools {
@@ -130,7 +131,7 @@ struct Pools {
     int* ttVals;
     Ctx* ctx;             // [nGames][2][BATCH]
     TrajEnt* traj;        // [nGames][2][BATCH][MAX_TRAJ]
-    u64* hist;            // [nGames][2][HIST_CAP]
+    u64* hist;            // [nGames][2][histCap]
     float* noise;         // [nGames][2][NOISE_CAP]
     u32* leafMoves;       // [nGames][2 batches][BATCH rows][2 boards][HM_MAX_MOVES]: filtered legal lists of the network leaves
     int* leafCounts;      // [nGames][2][BATCH][2]
@@ -292,7 +293,9 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCand
             // the frontier is an unordered array: the pop below takes the arg-best of the strict total order, which
             // is exactly the element a binary heap with that comparator would pop
             reinterpret_cast<HeapEnt*>(s.arena + h.heap)[h.heapSize++] = HeapEnt{jp, (uint16_t)a, (uint16_t)b};
-        } else if (sp + 2 <= 64) {
+        } else if (sp + 2 > 64) {
+            if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 64);   // skip chain longer than the explicit stack
+        } else {
             // the reference recurses (iA+1,iB) first, then (iA,iB+1): push in reverse for LIFO
             stack[sp++] = ((u32)a << 16) | (u32)(b + 1);
             stack[sp++] = ((u32)(a + 1) << 16) | (u32)b;
@@ -787,8 +790,8 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.ttVals = pl.ttVals + (size_t)g * prm.ttCap;
     s.ctx = pl.ctx + (size_t)g * 2 * BATCH;
     s.traj = pl.traj + (size_t)g * 2 * BATCH * MAX_TRAJ;
-    s.hist[0] = pl.hist + ((size_t)g * 2 + 0) * HIST_CAP;
-    s.hist[1] = pl.hist + ((size_t)g * 2 + 1) * HIST_CAP;
+    s.hist[0] = pl.hist + ((size_t)g * 2 + 0) * prm.histCap;
+    s.hist[1] = pl.hist + ((size_t)g * 2 + 1) * prm.histCap;
     s.noise[0] = pl.noise + ((size_t)g * 2 + 0) * NOISE_CAP;
     s.noise[1] = pl.noise + ((size_t)g * 2 + 1) * NOISE_CAP;
     s.leafMoves = pl.leafMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES;
@@ -1320,7 +1323,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
-    if (searchMask && !searchMask[g]) { s.g->status = ST_IDLE; rootHashOut[2 * g] = 0; rootHashOut[2 * g + 1] = 0; return; }
+    if ((searchMask && !searchMask[g]) || !s.g->live) { s.g->status = ST_IDLE; s.g->root = -1; rootHashOut[2 * g] = 0; rootHashOut[2 * g + 1] = 0; return; }
     const RulesTab& rt = s_rt;
     for (int i = lane; i < prm.ttCap; i += 64) s.ttVals[i] = -1;
     wave_fence();
@@ -1410,7 +1413,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
                 if (!consider) continue;
                 P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
                 make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
-                if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; }
+                if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; else atomicOr(&gm.overflow, 32); }   // candidate list truncated
             }
             __builtin_amdgcn_wave_barrier();
             int nh = (int)*hitCount;
@@ -1458,6 +1461,61 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     gm.status = ST_SEARCHING;
 }
 
+// Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
+// solver-aware, Q-veto, Q-weighting), the most-visited fallback and the index clamp.  One lane; the root has few edges.
+__device__ inline int best_move_index(const G& s, const Node& r, float qVetoDelta, float qValueWeight) {
+    if (!(r.flags & F_EXPANDED) || r.expanded <= 0) return -1;
+    const Edge* e = edges_of(s, r);
+    const int n = r.expanded;
+    int best = -1;
+    bool decided = false;
+    if (r.type == T_WIN) {
+        int shortest = 0x7fffffff;
+        for (int i = 0; i < r.cntTypes; ++i)
+            if (e[i].ctype == T_LOSS && s.nodes[e[i].child].endInPly < shortest) { shortest = s.nodes[e[i].child].endInPly; best = i; }
+        decided = best >= 0;
+    }
+    if (!decided && r.type == T_LOSS) {
+        best = 0;
+        int longest = 0;
+        for (int i = 0; i < n; ++i) { const int ep = s.nodes[e[i].child].endInPly; if (ep > longest) { longest = ep; best = i; } }
+        decided = true;
+    }
+    if (!decided) {
+        bool hasNonLosing = false;
+        for (int i = 0; i < n; ++i) hasNonLosing |= s.nodes[e[i].child].type != T_WIN;
+        auto eligible = [&](int i) { return !hasNonLosing || s.nodes[e[i].child].type != T_WIN; };
+        int first = 0;
+        while (first < n && !eligible(first)) ++first;
+        if (first == n) best = -1;
+        else {
+            int bestVisitIdx = first, maxVisits = e[first].visits, secondVisitIdx = -1;
+            for (int i = first + 1; i < n; ++i) {
+                if (!eligible(i)) continue;
+                if (e[i].visits > maxVisits) { secondVisitIdx = bestVisitIdx; maxVisits = e[i].visits; bestVisitIdx = i; }
+                else if (secondVisitIdx < 0 || e[i].visits > e[secondVisitIdx].visits) secondVisitIdx = i;
+            }
+            int bestQIdx = first;
+            float bestQ = e[first].q;
+            for (int i = first + 1; i < n; ++i) { if (!eligible(i)) continue; if (e[i].q > bestQ) { bestQ = e[i].q; bestQIdx = i; } }
+            best = bestVisitIdx;
+            bool done = false;
+            if (qVetoDelta > 0.0f && bestQIdx != bestVisitIdx && e[bestQIdx].q > e[bestVisitIdx].q + qVetoDelta && e[bestQIdx].visits > 1) { best = bestQIdx; done = true; }
+            if (!done && qValueWeight > 0.0f && secondVisitIdx >= 0 && e[secondVisitIdx].q > e[bestVisitIdx].q) {
+                const float qDifference = e[secondVisitIdx].q - e[bestVisitIdx].q;
+                const float adjusted = (float)e[secondVisitIdx].visits + qDifference * qValueWeight * (float)e[bestVisitIdx].visits;
+                if (adjusted > (float)e[bestVisitIdx].visits) best = secondVisitIdx;
+            }
+        }
+    }
+    if (best < 0) {                                       // agent.cc:872-880
+        int maxVisits = 0;
+        for (int i = 0; i < n; ++i) if (e[i].visits > maxVisits) { maxVisits = e[i].visits; best = i; }
+    }
+    if (best < 0 || best >= n) best = 0;                  // agent.cc:882-886
+    return best;
+}
+
 // root_edge_stats / root_q (agent.cc:1004-1024): out[g][0] = edge count, then per edge (moveA, moveB, visits).
 struct RootOut { int* counts; u32* moveA; u32* moveB; int* visits; float* q; float* prior; float* rootQ; int* info; int maxEdges; };
 __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut o) {
@@ -1480,7 +1538,9 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
     }
     if (lane == 0) {
         o.counts[g] = n; o.rootQ[g] = rq;
-        int* inf = o.info + (size_t)g * 12;
+        int* inf = o.info + (size_t)g * HM_SP_INFO_INTS;
+        inf[12] = gm.root >= 0 ? best_move_index(s, s.nodes[gm.root], prm.qVetoDelta, prm.qValueWeight) : -1;
+        inf[13] = inf[14] = inf[15] = 0;
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
         inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;
@@ -1488,17 +1548,18 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
 }
 
 // Board::push_move of the chosen joint action + team / time-advantage flip (selfplay.cc:694-716)
-__global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* moveA, const u32* moveB, const uint8_t* mask) {
+__global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* moveA, const u32* moveB, const uint8_t* mask, int* err) {
     __shared__ RulesTab s_rt;
     stage_table(&s_rt, pl.rules);
     __syncthreads();
     const int g = blockIdx.x;
     if (mask && !mask[g]) return;
     G s = make_view(pl, prm, g);
+    if (!s.g->live) return;
     Path p;
     path_reset(s, p);
     const u32 ma = moveA[g], mb = moveB[g];
-    if (p.jb.hlen[0] + 2 >= HIST_GAME || p.jb.hlen[1] + 2 >= HIST_GAME) { s.g->overflow |= 8; return; }
+    if (p.jb.hlen[0] + 2 >= prm.histGame || p.jb.hlen[1] + 2 >= prm.histGame) { if (threadIdx.x == 0) atomicOr(err, 1); return; }   // history pool full: nothing applied
     jb_make(s_rt, p.jb, ma, mb, true);
     store_pos(&s.g->pos[0], p.jb.bd[0]);
     store_pos(&s.g->pos[1], p.jb.bd[1]);
@@ -1529,7 +1590,7 @@ __global__ __launch_bounds__(64) void k_set_games(Pools pl, Params prm, const hm
         gm.hlen[b] = 1;
         gm.prefix[b] = mix_hash(HISTORY_HASH_SEED, k);
     }
-    gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0;
+    gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0; gm.live = 1;
 }
 
 // game state export: hm_board (for record planes / host bookkeeping) + terminal flags
@@ -1541,6 +1602,10 @@ __global__ __launch_bounds__(64) void k_game_state(Pools pl, Params prm, hm_boar
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
+    if (!s.g->live) {                                          // empty slot: no position to query
+        if (lane == 0) { hm_board z{}; out[g] = z; flags[g] = 0; }
+        return;
+    }
     Path p;
     path_reset(s, p);
     const bool mate = is_checkmate(s_rt, p.jb.bd, s.g->team, s.g->adv != 0, scratch);
@@ -1567,6 +1632,7 @@ __global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const u
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
+    if (!s.g->live) { if (lane == 0) { o.counts[g * 2] = o.counts[g * 2 + 1] = 0; o.onTurn[g * 2] = o.onTurn[g * 2 + 1] = 0; } return; }
     // reuse expand_leaf's prior computation through a throw-away context: replicate its first half
     P bd[2];
     load_pos(bd[0], &s.g->pos[0]);
@@ -1630,6 +1696,7 @@ __global__ __launch_bounds__(64) void k_action_terminal(Pools pl, Params prm, co
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
+    if (!s.g->live) { if (lane == 0) out[g] = 0; return; }
     Path p;
     path_reset(s, p);
     const int team = s.g->team;
@@ -1639,6 +1706,27 @@ __global__ __launch_bounds__(64) void k_action_terminal(Pools pl, Params prm, co
     wave_fence();
     const bool t = is_checkmate(s_rt, p.jb.bd, team ^ 1, !adv, scratch) || is_checkmate(s_rt, p.jb.bd, team, adv, scratch) || jb_is_draw(p.jb, 0);
     if (lane == 0) out[g] = t ? 1 : 0;
+}
+
+// test hook: classify_terminal_position (searchthread.cc:101-139) and Board::is_draw / repetition_count on each game's
+// CURRENT position with its real game history.  args[g] = {teamToPlay, rootTeam, rootAdv, searchPly};
+// out[g*4] = outcome | endInPly << 8, is_draw(searchPly), repetition_count(A), repetition_count(B)
+__global__ __launch_bounds__(64) void k_classify(Pools pl, Params prm, const int* args, int* out) {
+    __shared__ RulesTab s_rt;
+    __shared__ u32 scratch[6 * HM_MAX_MOVES];
+    stage_table(&s_rt, pl.rules);
+    __syncthreads();
+    const int g = blockIdx.x, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    if (!s.g->live) { if (lane == 0) { out[g * 4] = out[g * 4 + 1] = out[g * 4 + 2] = out[g * 4 + 3] = 0; } return; }
+    Path p;
+    path_reset(s, p);
+    const int* a = args + g * 4;
+    int e = 0;
+    const int to = classify_terminal_position(s_rt, p.jb, a[0], a[1], a[2] != 0, a[3], &e, scratch);
+    const bool draw = jb_is_draw(p.jb, a[3]);
+    const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
+    if (lane == 0) { out[g * 4] = to | (e << 8); out[g * 4 + 1] = draw ? 1 : 0; out[g * 4 + 2] = rcA; out[g * 4 + 3] = rcB; }
 }
 
 // test hook: Board queries on compact boards without history (tests/test_gpu_rules.py)
@@ -1765,8 +1853,10 @@ static int ensure_search_tables() {
 
 extern "C" {
 
-int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp** out) {
-    if (!out || n_games <= 0 || max_nodes <= 0) return hm_fail(HM_ERR_INVALID, "bad hm_sp_create arguments");
+int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp** out) { return hm_sp_create_ex(n_games, max_nodes, 0, cfg, out); }
+
+int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_search_config* cfg, hm_sp** out) {
+    if (!out || n_games <= 0 || max_nodes <= 0 || max_game_plies < 0) return hm_fail(HM_ERR_INVALID, "bad hm_sp_create arguments");
     if (int rc = ensure_search_tables()) return rc;
     hm_search_config c;
     if (cfg) c = *cfg; else hm_search_config_default(&c);
@@ -1776,6 +1866,8 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     Params& p = sp->prm;
     p.nGames = n_games;
     p.nodeCap = 3 * (max_nodes + 2 * BATCH) + 64;
+    p.histGame = std::max(HIST_GAME_MIN, max_game_plies + 8);        // one key per push on a board, at most one push per macro-ply
+    p.histCap = p.histGame + MAX_TRAJ + 8;
     int tt = 64;
     while (tt < 4 * p.nodeCap) tt <<= 1;
     p.ttCap = tt;
@@ -1783,6 +1875,7 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     p.cpuctInit = c.cpuct_init; p.cpuctBase = c.cpuct_base; p.fpuReduction = c.fpu_reduction; p.drawContempt = c.draw_contempt;
     p.wdlWeight = c.wdl_value_weight; p.mlDiscount = c.moves_left_discount;
     p.enableTranspositions = c.enable_transpositions; p.enableDynamicFpu = c.enable_dynamic_fpu; p.enableWdl = c.enable_wdl_eval;
+    p.qVetoDelta = 0.4f; p.qValueWeight = 1.0f;
     Pools& pl = sp->pl;
     const size_t G_ = (size_t)n_games;
     int rc = 0;
@@ -1793,7 +1886,7 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     rc |= dalloc(sp, &pl.ttVals, G_ * p.ttCap);
     rc |= dalloc(sp, &pl.ctx, G_ * 2 * BATCH);
     rc |= dalloc(sp, &pl.traj, G_ * 2 * BATCH * MAX_TRAJ);
-    rc |= dalloc(sp, &pl.hist, G_ * 2 * HIST_CAP);
+    rc |= dalloc(sp, &pl.hist, G_ * 2 * (size_t)p.histCap);
     rc |= dalloc(sp, &pl.noise, G_ * 2 * NOISE_CAP);
     rc |= dalloc(sp, &pl.leafMoves, G_ * 2 * BATCH * 2 * HM_MAX_MOVES);
     rc |= dalloc(sp, &pl.leafCounts, G_ * 2 * BATCH * 2);
@@ -1819,8 +1912,8 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
     ro.maxEdges = sp->maxEdges;
     rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
     rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
-    rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * 12);
-    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 1); rc |= dalloc(sp, &sp->d_target, G_);
+    rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * HM_SP_INFO_INTS);
+    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 2);   // [0] active games, [1] hm_sp_apply error flag rc |= dalloc(sp, &sp->d_target, G_);
     rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
     rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
@@ -1923,7 +2016,7 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     if (q) HIPCHK(hipMemcpy(q, sp->ro.q, 4 * G_ * E, hipMemcpyDeviceToHost));
     if (prior) HIPCHK(hipMemcpy(prior, sp->ro.prior, 4 * G_ * E, hipMemcpyDeviceToHost));
     if (root_q) HIPCHK(hipMemcpy(root_q, sp->ro.rootQ, 4 * G_, hipMemcpyDeviceToHost));
-    if (info) HIPCHK(hipMemcpy(info, sp->ro.info, 4 * G_ * 12, hipMemcpyDeviceToHost));
+    if (info) HIPCHK(hipMemcpy(info, sp->ro.info, 4 * G_ * HM_SP_INFO_INTS, hipMemcpyDeviceToHost));
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
@@ -1968,9 +2061,12 @@ int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const u
     HIPCHK(hipMemcpy(sp->d_moveA, move_a, 4 * G_, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(sp->d_moveB, move_b, 4 * G_, hipMemcpyHostToDevice));
     if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr);
+    HIPCHK(hipMemset(sp->d_active + 1, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr, sp->d_active + 1);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, sp->d_active + 1, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
     return 0;
 }
 
@@ -2008,6 +2104,23 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
     hipLaunchKernelGGL(k_action_terminal, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, sp->d_term);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, sp->d_term, 4 * G_, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hm_sp_classify(hm_sp* sp, const int* args4, int* out4) {
+    if (!sp || !args4 || !out4) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    int *d_args = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_args, 16 * G_));
+    if (hipMalloc(&d_out, 16 * G_) != hipSuccess) { (void)hipFree(d_args); return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(d_args, args4, 16 * G_, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_classify, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, d_args, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out4, d_out, 16 * G_, hipMemcpyDeviceToHost);
+    (void)hipFree(d_args); (void)hipFree(d_out);
+    if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("hm_sp_classify: ") + hipGetErrorString(e));
     return 0;
 }
 

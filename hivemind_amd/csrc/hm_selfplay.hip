@@ -317,7 +317,8 @@ int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* sc
     s->G = c.concurrent_games;
     s->runId = c.seed != 0 ? c.seed : static_cast<uint64_t>(std::chrono::system_clock::now().time_since_epoch().count());
     const int maxNodes = (int)std::llround((double)c.nodes * (1.0 + c.node_random_factor)) + 1;
-    if (int rc = hm_sp_create(s->G, maxNodes, &s->scfg, &s->sp)) { delete s; return rc; }
+    if (c.max_macro_plies > (1u << 20)) { delete s; return hm_fail(HM_ERR_INVALID, "max_macro_plies too large"); }
+    if (int rc = hm_sp_create_ex(s->G, maxNodes, (int)c.max_macro_plies, &s->scfg, &s->sp)) { delete s; return rc; }
     if (hipMalloc(&s->d_boards, sizeof(hm_board) * s->G) != hipSuccess || hipMalloc(&s->d_u8, (size_t)HM_PLANE_VALUES * s->G) != hipSuccess
         || hipMalloc(&s->d_rows[0], sizeof(int32_t) * s->G) != hipSuccess || hipMalloc(&s->d_rows[1], sizeof(int32_t) * s->G) != hipSuccess) {
         hm_sp_destroy(s->sp); delete s; return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed");
@@ -353,7 +354,7 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
     std::vector<int> flags(G), counts(G), term(G);
     std::vector<uint8_t> mask(G), u8planes((size_t)G * HM_PLANE_VALUES);
     std::vector<hm_move> mA((size_t)G * E), mB((size_t)G * E), actA(G), actB(G);
-    std::vector<int> visits((size_t)G * E), target(G), info((size_t)G * 12);
+    std::vector<int> visits((size_t)G * E), target(G), info((size_t)G * HM_SP_INFO_INTS);
     std::vector<float> rootQ(G);
     std::vector<uint64_t> seeds(G);
     std::vector<hm_move> rawMoves((size_t)G * 2 * HM_MAX_MOVES);
@@ -490,11 +491,11 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
         for (int g = 0; g < G; ++g) {
             if (!mask[g]) continue;
             Slot& sl = s->slots[g];
-            if (info[(size_t)g * 12 + 8]) return hm_fail(HM_ERR_OVERFLOW, "search pool overflow in game slot " + std::to_string(g) + " (flags " + std::to_string(info[(size_t)g * 12 + 8]) + ")");
+            if (info[(size_t)g * HM_SP_INFO_INTS + 8]) return hm_fail(HM_ERR_OVERFLOW, "search pool overflow in game slot " + std::to_string(g) + " (flags " + std::to_string(info[(size_t)g * HM_SP_INFO_INTS + 8]) + ")");
             s->res.searched_positions += 1;
-            s->res.eval_rows += (uint64_t)info[(size_t)g * 12 + 2];
-            s->res.nodes_visited += (uint64_t)info[(size_t)g * 12 + 10];
-            s->res.edges_scanned += (uint64_t)info[(size_t)g * 12 + 11];
+            s->res.eval_rows += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 2];
+            s->res.nodes_visited += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 10];
+            s->res.edges_scanned += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 11];
             const int n = counts[g];
             if (n == 0) { sl.winner = sl.team == HM_WHITE ? 1 : 0; sl.termination = 4; finish_game(s, sl); continue; }
             const hm_move* ea = mA.data() + (size_t)g * E;

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import BOARD_DTYPE, MAX_MOVES, PLANE_VALUES, POLICY_VALUES, HivemindError, check, lib
 
 BATCH = 8   # SearchParams::BATCH_SIZE (search_params.h:26)
+INFO_INTS = 16   # HM_SP_INFO_INTS
 ST_IDLE, ST_SEARCHING, ST_FINISHING, ST_DONE, ST_NOACTION, ST_ERROR = range(6)
 
 
@@ -29,6 +30,7 @@ _vp, _i = C.c_void_p, C.c_int
 _SIGS = {
     "hm_search_config_default": (None, [C.POINTER(SearchConfig)]),
     "hm_sp_create": (_i, [_i, _i, C.POINTER(SearchConfig), C.POINTER(_vp)]),
+    "hm_sp_create_ex": (_i, [_i, _i, _i, C.POINTER(SearchConfig), C.POINTER(_vp)]),
     "hm_sp_destroy": (_i, [_vp]),
     "hm_sp_set_games": (_i, [_vp, _vp, _vp]),
     "hm_sp_begin_search": (_i, [_vp, _vp, _vp, C.c_float, C.c_float, _vp]),
@@ -43,6 +45,7 @@ _SIGS = {
     "hm_sp_raw_policy": (_i, [_vp] * 8),
     "hm_sp_action_terminal": (_i, [_vp, _vp, _vp, _vp]),
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
+    "hm_sp_classify": (_i, [_vp, _vp, _vp]),
     "hm_sp_profile": (_i, [_vp, _i]),
     "hm_sp_trace_select": (_i, [_i]),
     "hm_sp_trace": (_i, [_vp, _i]),
@@ -66,14 +69,14 @@ def _p(a):
 class SearchEngine:
     """G concurrent games, each searched by one wavefront; all games advance in lockstep."""
 
-    def __init__(self, n_games: int, max_nodes: int, config: SearchConfig = None, device=None):
+    def __init__(self, n_games: int, max_nodes: int, config: SearchConfig = None, device=None, max_game_plies: int = 0):
         from . import _require_init
         _require_init()
         self.G = n_games
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.h = _vp()
         cfg = config or default_config()
-        check(lib.hm_sp_create(n_games, max_nodes, C.byref(cfg), C.byref(self.h)))
+        check(lib.hm_sp_create_ex(n_games, max_nodes, max_game_plies, C.byref(cfg), C.byref(self.h)))
         self.max_edges = lib.hm_sp_max_edges(self.h)
         rows = n_games * BATCH
         self.planes = [torch.zeros((rows, 74, 8, 8), dtype=torch.float16, device=self.device) for _ in range(2)]
@@ -154,7 +157,7 @@ class SearchEngine:
         G, E = self.G, self.max_edges
         out = dict(counts=np.zeros(G, np.int32), move_a=np.zeros((G, E), np.uint32), move_b=np.zeros((G, E), np.uint32),
                    visits=np.zeros((G, E), np.int32), q=np.zeros((G, E), np.float32), prior=np.zeros((G, E), np.float32),
-                   root_q=np.zeros(G, np.float32), info=np.zeros((G, 12), np.int32))
+                   root_q=np.zeros(G, np.float32), info=np.zeros((G, INFO_INTS), np.int32))
         check(lib.hm_sp_root_stats(self.h, *[out[k].ctypes.data for k in
                                              ("counts", "move_a", "move_b", "visits", "q", "prior", "root_q", "info")], E))
         return out
@@ -170,6 +173,15 @@ class SearchEngine:
         check(lib.hm_sp_raw_policy(self.h, pi_a.data_ptr(), pi_b.data_ptr(), moves.ctypes.data, probs.ctypes.data,
                                    caps.ctypes.data, counts.ctypes.data, on_turn.ctypes.data))
         return moves, probs, caps, counts, on_turn
+
+    def classify(self, team, root_team, root_adv, ply):
+        """Test hook (hm_sp_classify): classify_terminal_position / is_draw / repetition counts on the games' current
+        positions with their game history.  Arguments broadcast over games.  -> int32 [G, 4]."""
+        args = np.ascontiguousarray(np.stack(np.broadcast_arrays(*[np.asarray(x, np.int32) for x in (team, root_team, root_adv, ply)],
+                                                                 np.zeros(self.G, np.int32))[:4], axis=1), dtype=np.int32)
+        out = np.zeros((self.G, 4), np.int32)
+        check(lib.hm_sp_classify(self.h, args.ctypes.data, out.ctypes.data))
+        return out
 
     def action_terminal(self, move_a, move_b):
         a = np.ascontiguousarray(move_a, dtype=np.uint32)

@@ -181,6 +181,9 @@ void hm_search_config_default(hm_search_config* cfg);
 
 /* n_games game slots, trees sized for searches of up to max_nodes nodes. */
 int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp** out);
+/* As hm_sp_create, with the per-board game history sized for games of up to max_game_plies macro-plies
+ * (Board::positionHistory grows by one key per push, board.h:95-102); 0 = the default of 1024 keys. */
+int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_search_config* cfg, hm_sp** out);
 int hm_sp_destroy(hm_sp* sp);
 /* (Re)start games from host boards[n_games] (Board::set, board.cc:27-49: history restarts);
  * team / time_adv of each hm_board give the side to act.  mask[g]==0 leaves game g alone. */
@@ -199,13 +202,17 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
 /* Games still searching after the last hm_sp_process (synchronises). */
 int hm_sp_active(hm_sp* sp, int* active);
 /* Agent::root_edge_stats / root_q (agent.cc:1004-1024) for all games -> host arrays
- * [n_games][max_edges]; info[g][12] = status, nodes, eval rows, same-batch collisions,
+ * [n_games][max_edges]; info[g][HM_SP_INFO_INTS] = status, nodes, eval rows, same-batch collisions,
  * reservation collisions, node count, root type, root visits, overflow flags, max depth,
- * tree nodes visited and edges scanned during selection (traffic accounting). */
+ * tree nodes visited and edges scanned during selection (traffic accounting), [12] = index of the
+ * joint action Agent::run_search returns (get_best_move_idx_with_q_weight, node.h:656-754 with
+ * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13..15] reserved. */
+#define HM_SP_INFO_INTS 16
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
                      float* root_q, int* info, int max_edges);
-/* Board::push_move of the chosen joint action, then team / time-advantage flip (selfplay.cc:694-716). */
+/* Board::push_move of the chosen joint action, then team / time-advantage flip (selfplay.cc:694-716).
+ * HM_ERR_OVERFLOW when a game's history pool is full (nothing is applied to that game). */
 int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask);
 /* Current boards (+ rep counts, last moves) and flags: bit0 is_checkmate(team, adv), bit1 is_draw()
  * (selfplay.cc:608-616).  d_boards_out (device, optional) receives the same hm_board array. */
@@ -219,6 +226,10 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
 /* Test hook: Board::is_checkmate x4, in-check x2, classify_terminal_position x2 and hash keys for
  * history-free boards (d_out: n*8 ints, d_keys: n*4 u64: hash_key(adv=0), hash_key(adv=1), repetition keys). */
 int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
+/* Test hook: classify_terminal_position (searchthread.cc:101-139), Board::is_draw(ply) and repetition_count on every
+ * game's CURRENT position with its real game history.  args4[g] = {teamToPlay, rootTeam, rootAdv, searchPly} (host);
+ * out4[g] = {outcome | endInPly << 8, is_draw, repetition_count(A), repetition_count(B)} (host). */
+int hm_sp_classify(hm_sp* sp, const int* args4, int* out4);
 
 /* Diagnostics of the tree kernels (no reference counterpart; all no-ops / zeros in the product build).
  * hm_sp_profile: cycle accounting of game slot 0, out64[0..31] cycles and out64[32..63] call counts per probe

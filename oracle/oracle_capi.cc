@@ -177,6 +177,7 @@ int ora_search_edges(void* sp, uint32_t* moveA, uint32_t* moveB, int* visits, fl
     return (int)e.size();
 }
 float ora_search_root_q(void* sp) { return static_cast<Search*>(sp)->root_q(); }
+int ora_search_best_move(void* sp) { return static_cast<Search*>(sp)->best_move_index(); }
 void ora_search_info(void* sp, int* out /*8*/) {
     Search* s = static_cast<Search*>(sp);
     out[0] = s->nodesSearched; out[1] = s->evalRows; out[2] = s->evalCalls; out[3] = s->sameBatchCollisions;
@@ -244,4 +245,7 @@ double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, i
 
 #if __has_include("search.hpp")
 #include "oracle_lab.cc"
+#if __has_include("selfplay.hpp")
+#include "oracle_selfplay.cc"
+#endif
 #endif

@@ -1001,6 +1001,19 @@ public:
         return out;
     }
     float root_q() const { return root ? root->Q() : 0.0f; }
+    // index of the joint action Agent::run_search returns (agent.cc:859-889)
+    int best_move_index() const {
+        if (!root || !root->isExpanded) return -1;
+        if (root->childVisits.empty() || root->children.empty()) return -1;
+        const size_t n = std::min(root->childVisits.size(), root->children.size());
+        int best = root->get_best_move_idx_with_q_weight(cfg.qVetoDelta, cfg.qValueWeight);
+        if (best < 0) {
+            int maxVisits = 0;
+            for (size_t i = 0; i < n; ++i) if (root->childVisits[i] > maxVisits) { maxVisits = root->childVisits[i]; best = (int)i; }
+        }
+        if ((size_t)best >= root->gen.generated.size()) best = 0;
+        return best;
+    }
 };
 
 }  // namespace hmo

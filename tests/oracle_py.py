@@ -175,6 +175,7 @@ lib.ora_search_run.restype, lib.ora_search_run.argtypes = _i, [_vp, _vp, _i, _i,
 lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]
 lib.ora_search_root_q.restype, lib.ora_search_root_q.argtypes = C.c_float, [_vp]
 lib.ora_search_info.restype, lib.ora_search_info.argtypes = None, [_vp, _vp]
+lib.ora_search_best_move.restype, lib.ora_search_best_move.argtypes = _i, [_vp]
 lib.ora_search_trace.restype, lib.ora_search_trace.argtypes = _i, [_vp, _vp, _i]
 lib.ora_classify.restype, lib.ora_classify.argtypes = _i, [_vp, _i, _i, _i, _i]
 lib.ora_search_ctx_trace.restype, lib.ora_search_ctx_trace.argtypes = _i, [_vp, _vp, _i]
@@ -237,6 +238,7 @@ class Search:
                     reservation=int(o[4]), node_count=int(o[5]), root_type=int(o[6]), root_visits=int(o[7]))
 
     def root_q(self): return float(lib.ora_search_root_q(self.h))
+    def best_move(self): return int(lib.ora_search_best_move(self.h))
 
 
 def hash_evaluator(planes):
@@ -246,3 +248,60 @@ def hash_evaluator(planes):
     w = np.zeros((n, 3), np.uint16); m = np.zeros(n, np.uint16)
     lib.ora_hash_evaluator(planes.ctypes.data, n, v.ctypes.data, a.ctypes.data, b.ctypes.data, w.ctypes.data, m.ctypes.data)
     return v, a, b, w, m
+
+
+# ---- self-play loop oracle (oracle/selfplay.hpp) ------------------------------------------------
+class SelfPlayCfg(C.Structure):
+    """Layout of hm_selfplay_config (include/hivemind_amd.h) = SelfPlayConfig (tools/selfplay.h:10-31) + sharding."""
+    _fields_ = [("games", C.c_uint64), ("nodes", C.c_uint64), ("max_macro_plies", C.c_uint64), ("chunk_samples", C.c_uint64),
+                ("raw_policy_mean_macro_plies", C.c_double), ("raw_policy_max_macro_plies", C.c_uint64),
+                ("raw_policy_high_temperature_probability", C.c_double),
+                ("mcts_temperature", C.c_double), ("mcts_temperature_decay", C.c_double), ("mcts_temperature_plies", C.c_uint64),
+                ("resign_threshold", C.c_float), ("resign_consecutive_plies", C.c_uint64), ("resign_disable_fraction", C.c_double),
+                ("node_random_factor", C.c_double), ("dirichlet_alpha", C.c_float), ("dirichlet_epsilon", C.c_float),
+                ("seed", C.c_uint64), ("rank", C.c_int), ("world", C.c_int), ("concurrent_games", C.c_int)]
+
+
+def selfplay_cfg(**kw):
+    """Reference defaults (tools/selfplay.h:10-31) with overrides."""
+    c = SelfPlayCfg(games=1, nodes=800, max_macro_plies=400, chunk_samples=16384, raw_policy_mean_macro_plies=8.0,
+                    raw_policy_max_macro_plies=30, raw_policy_high_temperature_probability=0.05, mcts_temperature=1.0,
+                    mcts_temperature_decay=0.93, mcts_temperature_plies=20, resign_threshold=-0.90, resign_consecutive_plies=3,
+                    resign_disable_fraction=0.10, node_random_factor=0.05, dirichlet_alpha=0.3, dirichlet_epsilon=0.25,
+                    seed=0, rank=0, world=1, concurrent_games=64)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+lib.ora_selfplay_new.restype, lib.ora_selfplay_new.argtypes = _vp, [_vp, _i, _i]
+lib.ora_selfplay_free.restype, lib.ora_selfplay_free.argtypes = None, [_vp]
+lib.ora_selfplay_set_callback.restype, lib.ora_selfplay_set_callback.argtypes = None, [_vp, EVAL_CB]
+lib.ora_selfplay_game.restype, lib.ora_selfplay_game.argtypes = C.c_int64, [_vp, _u64, _vp, _u64, _vp]
+lib.ora_selfplay_last_actions.restype, lib.ora_selfplay_last_actions.argtypes = _i, [_vp, _vp, _vp, _i]
+
+
+class SelfPlayOracle:
+    """Sequential restatement of run_selfplay's game loop (per-game RNG streams), hash evaluator by default."""
+
+    def __init__(self, cfg, tie_mode=1, exp_mode=1):
+        self.cfg = cfg
+        self.h = lib.ora_selfplay_new(C.byref(cfg), tie_mode, exp_mode)
+
+    def __del__(self):
+        try:
+            lib.ora_selfplay_free(self.h)
+        except Exception:
+            pass
+
+    def game(self, index):
+        """-> (record bytes of the game, dict(samples, raw_plies, winner, termination, nodes), actions [(moveA, moveB, raw)])"""
+        cap = 1 << 22
+        buf = np.zeros(cap, np.uint8)
+        info = np.zeros(8, np.int64)
+        n = lib.ora_selfplay_game(self.h, index, buf.ctypes.data, cap, info.ctypes.data)
+        assert n >= 0, n
+        a = np.zeros(2048, np.uint32); b = np.zeros(2048, np.uint32); r = np.zeros(2048, np.uint8)
+        k = lib.ora_selfplay_last_actions(a.ctypes.data, b.ctypes.data, r.ctypes.data, 2048)
+        return (buf[:n].tobytes(), dict(samples=int(info[0]), raw_plies=int(info[1]), winner=int(info[2]), termination=int(info[3]), nodes=int(info[4])),
+                list(zip(a[:k].tolist(), b[:k].tolist(), r[:k].tolist())))

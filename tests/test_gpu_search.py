@@ -79,6 +79,7 @@ def test_search_matches_oracle(hm, nodes, noise):
                 and info[1] == oi["nodes"] and info[2] == oi["eval_rows"] and info[5] == oi["node_count"])
         assert same, (g, n, len(e["visits"]), info, oi, st["visits"][g, :n], e["visits"])
         assert st["root_q"][g] == np.float32(s.root_q())
+        assert info[12] == s.best_move(), (g, info[12], s.best_move())      # Agent::run_search's returned action (agent.cc:859-889)
         exact += 1
     assert exact == G
     eng.close()
@@ -104,3 +105,46 @@ def test_collect_row_counts(hm):
     st = eng.root_stats()
     # rows written after a game's last processed batch (aborted lookahead) are counted by collect but not evaluated
     assert (total >= st["info"][:, 2]).all() and (total - st["info"][:, 2] <= 8).all(), (total, st["info"][:, 2])
+
+
+def test_search_with_non_finite_logits_matches_oracle(hm):
+    """normalize_logits' fallbacks inside the search (utils.h:127-167; reference known answers test_move_gen.cc:643-657 pin
+    the oracle): the evaluator poisons a share of the policy / value / wdl outputs with NaN and infinities; GPU expansion
+    (lane-parallel masked softmax, shape_value) must still equal the oracle bit for bit."""
+    import torch
+
+    def by_content(h):
+        v, a, b, w, m = O.hash_evaluator(h)
+        v, a, b, w, m = v.copy(), a.copy(), b.copy(), w.copy(), m.copy()
+        for r in range(len(h)):
+            k = int(h[r].astype(np.uint64).sum() % 8)
+            if k == 0:
+                a[r, :] = 0x7E00
+            elif k == 1:
+                a[r, 0::3] = 0xFC00; b[r, 1::5] = 0x7E00
+            elif k == 2:
+                b[r, :] = 0xFC00; w[r, 1] = 0x7E00
+            elif k == 3:
+                v[r] = 0x7C00; a[r, 2::7] = 0x7C00
+        return v, a, b, w, m
+    G = 16
+    roots = _roots(G, 4711)
+    eng = hm.SearchEngine(G, 400)
+    eng.set_games(roots)
+    eng.begin_search(200)
+    eng.run(lambda planes: tuple(torch.from_numpy(x.view(np.float16)).cuda() for x in by_content(planes.cpu().numpy().view(np.uint16).reshape(-1, 4736))))
+    st = eng.root_stats()
+    for g in range(G):
+        b = O.Board()
+        b.from_compact(roots[g:g + 1])
+        s = O.Search(1, 1)
+        s.set_evaluator(by_content)
+        ok = s.run(b, int(roots["team"][g]), bool(roots["time_adv"][g]), 200)
+        if not ok:
+            assert st["info"][g][0] == 4
+            continue
+        e = s.edges()
+        n = st["counts"][g]
+        assert n == len(e["visits"]) and np.array_equal(st["visits"][g, :n], e["visits"]), (g, st["visits"][g, :n], e["visits"])
+        assert np.array_equal(st["prior"][g, :n], e["prior"]) and np.array_equal(st["q"][g, :n], e["q"]), g
+    eng.close()
