@@ -381,14 +381,17 @@ struct Pos {
         std::istringstream ss(fen);
         std::string placement, stmS, cast = "-", epS = "-";
         ss >> placement >> stmS;
-        int s = 56;
+        int s = 56, slashes = 0;
         size_t i = 0;
         static const std::string pcs = " PNBRQK";
         for (; i < placement.size(); ++i) {
             char ch = placement[i];
             if (ch == '[') break;
             if (isdigit((unsigned char)ch)) s += ch - '0';
-            else if (ch == '/') s -= 16;
+            else if (ch == '/') {
+                if (++slashes == 8) { ++i; break; }       // pieces in hand after an additional slash (position.cpp:290-296)
+                s -= 16;
+            }
             else {
                 size_t idx = pcs.find((char)toupper((unsigned char)ch));
                 if (idx == std::string::npos || idx == 0) continue;
