@@ -271,21 +271,28 @@ __device__ inline void gen_grow(G& s, u32& off, u32& cap, u32 size, u32 elemByte
     for (u32 i = 0; i < words; ++i) s.arena[noff + i] = s.arena[off + i];
     off = noff; cap = ncap;
 }
-__device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCandidate :146-177 (recursion -> explicit stack)
-    uint32_t stack[64];
-    int sp = 0;
-    stack[sp++] = ((u32)iA << 16) | (u32)iB;
-    while (sp > 0) {
-        const u32 key = stack[--sp];
+// pushCandidate (:146-177).  The reference recurses through invalid pairs (sit-rule violations) to their successors; what a
+// push leaves behind is order-free: `visited` is a set and the frontier is popped by a strict total order, so only the
+// closure matters.  It is computed breadth-first with the visited list itself as the work queue — no recursion stack, so
+// no depth limit (a column of quiet-move x pass pairs is as long as the board's move list).
+__device__ inline bool gen_visit(G& s, GenHdr& h, int a, int b) {
+    if (a >= h.nA || b >= h.nB) return true;
+    const u32 key = ((u32)a << 16) | (u32)b;
+    u32* vis = reinterpret_cast<u32*>(s.arena + h.visited);
+    bool seen = false;
+    for (u32 i = threadIdx.x & 63; i < h.visSize; i += 64) seen |= vis[i] == key;   // lane-parallel membership test
+    if (wave_any(seen)) return true;
+    if (h.visSize >= h.visCap) { gen_grow(s, h.visited, h.visCap, h.visSize, 4); vis = reinterpret_cast<u32*>(s.arena + h.visited); }
+    if (h.visSize >= h.visCap) return false;              // arena exhausted (overflow flagged by arena_alloc)
+    vis[h.visSize++] = key;                               // every lane stores the same word: each lane later re-reads only its own stores
+    return true;
+}
+__device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {
+    u32 q = h.visSize;
+    if (!gen_visit(s, h, iA, iB)) return;
+    for (; q < h.visSize; ++q) {
+        const u32 key = reinterpret_cast<const u32*>(s.arena + h.visited)[q];
         const int a = key >> 16, b = key & 0xffff;
-        if (a >= h.nA || b >= h.nB) continue;
-        u32* vis = reinterpret_cast<u32*>(s.arena + h.visited);
-        bool seen = false;
-        for (u32 i = threadIdx.x & 63; i < h.visSize; i += 64) seen |= vis[i] == key;   // lane-parallel membership test
-        if (wave_any(seen)) continue;
-        if (h.visSize >= h.visCap) { gen_grow(s, h.visited, h.visCap, h.visSize, 4); vis = reinterpret_cast<u32*>(s.arena + h.visited); }
-        if (h.visSize >= h.visCap) return;
-        vis[h.visSize++] = key;
         const float jp = joint_prior(s, h, a, b, nullptr, nullptr);
         if (jp >= 0.0f) {
             if (h.heapSize >= h.heapCap) gen_grow(s, h.heap, h.heapCap, h.heapSize, 8);
@@ -293,12 +300,8 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {   // pushCand
             // the frontier is an unordered array: the pop below takes the arg-best of the strict total order, which
             // is exactly the element a binary heap with that comparator would pop
             reinterpret_cast<HeapEnt*>(s.arena + h.heap)[h.heapSize++] = HeapEnt{jp, (uint16_t)a, (uint16_t)b};
-        } else if (sp + 2 > 64) {
-            if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 64);   // skip chain longer than the explicit stack
         } else {
-            // the reference recurses (iA+1,iB) first, then (iA,iB+1): push in reverse for LIFO
-            stack[sp++] = ((u32)a << 16) | (u32)(b + 1);
-            stack[sp++] = ((u32)(a + 1) << 16) | (u32)b;
+            if (!gen_visit(s, h, a + 1, b) || !gen_visit(s, h, a, b + 1)) return;
         }
     }
 }

@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cerrno>
 #include <fstream>
+#include <sys/stat.h>
 #include <map>
 #include <numeric>
 #include <random>
@@ -106,8 +108,14 @@ struct hm_selfplay {
     int G = 0;
     std::vector<Slot> slots;
     uint64_t nextGame = 0, gamesDone = 0, runId = 0;
-    std::vector<uint8_t> records;
-    uint64_t recordCount = 0;
+    std::vector<uint8_t> records;             // serialized samples of finished games not yet handed to a chunk sink
+    std::vector<size_t> sampleEnd;            // byte offset just past each pending sample
+    uint64_t recordCount = 0;                 // == sampleEnd.size()
+    hm_chunk_fn sink = nullptr;               // ChunkWriter::flush replacement (selfplay.cc:105-151)
+    void* sinkUser = nullptr;
+    std::string outDir;                       // built-in sink: <outDir>/training_data/chunk_<runId>_<idx>.hvm
+    uint64_t chunkIndex = 0;
+    int sinkError = 0;
     hm_selfplay_result res{};
     hm_board* d_boards = nullptr;
     uint8_t* d_u8 = nullptr;
@@ -150,16 +158,40 @@ static bool start_game(hm_selfplay* s, Slot& sl, hm_board& out) {
     return true;
 }
 
+// ChunkWriter::flush (selfplay.cc:105-151): the first `count` pending samples leave as one chunk
+static void flush_chunk(hm_selfplay* s, size_t count) {
+    if (count == 0 || count > s->sampleEnd.size()) return;
+    const size_t nbytes = s->sampleEnd[count - 1];
+    int rc = 0;
+    if (s->sink) rc = s->sink(s->sinkUser, s->records.data(), nbytes, count, s->chunkIndex);
+    else {
+        char name[96];
+        std::snprintf(name, sizeof name, "/training_data/chunk_%llu_%06llu.hvm", (unsigned long long)s->runId, (unsigned long long)s->chunkIndex);
+        rc = hm_hvm4_write_chunk((s->outDir + name).c_str(), s->records.data(), nbytes, count);
+    }
+    if (rc && !s->sinkError) s->sinkError = rc;
+    s->chunkIndex++;
+    s->res.chunks_flushed += 1;
+    s->records.erase(s->records.begin(), s->records.begin() + (std::ptrdiff_t)nbytes);
+    s->sampleEnd.erase(s->sampleEnd.begin(), s->sampleEnd.begin() + (std::ptrdiff_t)count);
+    for (size_t& e : s->sampleEnd) e -= nbytes;
+    s->recordCount = s->sampleEnd.size();
+}
+static bool has_sink(const hm_selfplay* s) { return s->sink != nullptr || !s->outDir.empty(); }
+
 static void finish_game(hm_selfplay* s, Slot& sl) {   // selfplay.cc:726-734
+    const size_t perChunk = std::max<size_t>(1, (size_t)s->cfg.chunk_samples);
     for (size_t i = 0; i < sl.samples.size(); ++i) {
         Sample& sm = sl.samples[i];
         sm.outcome = sl.winner < 0 ? 0 : (sm.team == sl.winner ? 1 : -1);
         sm.wdl = static_cast<uint8_t>(sm.outcome + 1);
         sm.movesLeft = static_cast<uint16_t>(std::min<size_t>(sl.samples.size() - i, 65535));
         serialize(s->records, sm);
+        s->sampleEnd.push_back(s->records.size());
         s->res.total_nodes += sm.nodes;
+        if (has_sink(s) && s->sampleEnd.size() >= perChunk) flush_chunk(s, perChunk);   // ChunkWriter::append :78-85
     }
-    s->recordCount += sl.samples.size();
+    s->recordCount = s->sampleEnd.size();
     s->res.samples += sl.samples.size();
     s->res.games += 1;
     s->res.raw_plies += sl.rawPlies;
@@ -344,12 +376,47 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     return 0;
 }
 
+static int selfplay_run_impl(hm_selfplay* s);
+
+int hm_selfplay_set_chunk_sink(hm_selfplay* s, hm_chunk_fn fn, void* user) {
+    if (!s) return hm_fail(HM_ERR_INVALID, "null argument");
+    s->sink = fn; s->sinkUser = user;
+    return 0;
+}
+int hm_selfplay_set_output_directory(hm_selfplay* s, const char* dir) {
+    if (!s) return hm_fail(HM_ERR_INVALID, "null argument");
+    s->outDir = dir ? dir : "";
+    if (!s->outDir.empty()) {                                  // ChunkWriter ctor: create_directories(directory_) :74
+        const std::string td = s->outDir + "/training_data";
+        std::string cur;
+        for (size_t i = 0; i <= td.size(); ++i)
+            if (i == td.size() || td[i] == '/') { if (!cur.empty() && ::mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return hm_fail(HM_ERR_INVALID, "Unable to create " + cur); if (i < td.size()) cur += '/'; }
+            else cur += td[i];
+    }
+    return 0;
+}
+
+// run_selfplay (selfplay.cc:558-748).  Whatever the outcome, the samples of every finished game are handed to the chunk
+// sink before returning (ChunkWriter::finish :87-91), so an error late in a run does not discard the games before it.
 int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
     if (!s) return hm_fail(HM_ERR_INVALID, "null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = selfplay_run_impl(s);
+    const std::string msg = rc ? std::string(hm_last_error()) : std::string();
+    if (has_sink(s) && !s->sampleEnd.empty()) flush_chunk(s, s->sampleEnd.size());
+    s->res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    s->res.record_bytes = s->records.size();
+    for (int i = 0; i < 5; ++i) s->res.terminations[i] = s->termCounts[i];
+    if (out) *out = s->res;
+    if (rc) return hm_fail(rc, msg);
+    if (s->sinkError) return hm_fail(HM_ERR_STATE, "chunk sink failed (" + std::to_string(s->sinkError) + ")");
+    return 0;
+}
+
+static int selfplay_run_impl(hm_selfplay* s) {
     const hm_selfplay_config& c = s->cfg;
     const int G = s->G;
     const int E = hm_sp_max_edges(s->sp);
-    auto t0 = std::chrono::steady_clock::now();
     std::vector<hm_board> boards(G);
     std::vector<int> flags(G), counts(G), term(G);
     std::vector<uint8_t> mask(G), u8planes((size_t)G * HM_PLANE_VALUES);
@@ -566,10 +633,6 @@ int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
             if (r) if (int rc = hm_sp_set_games(s->sp, init.data(), mask.data())) return rc;
         }
     }
-    s->res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    s->res.record_bytes = s->records.size();
-    for (int i = 0; i < 5; ++i) s->res.terminations[i] = s->termCounts[i];
-    if (out) *out = s->res;
     return 0;
 }
 

@@ -37,15 +37,19 @@ class SelfPlayResult(C.Structure):
                 ("record_bytes", C.c_uint64), ("terminations", C.c_uint64 * 5), ("seconds", C.c_double),
                 ("collect_ms", C.c_double), ("eval_ms", C.c_double), ("process_ms", C.c_double),
                 ("nodes_visited", C.c_uint64), ("edges_scanned", C.c_uint64),
-                ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double)]
+                ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double),
+                ("chunks_flushed", C.c_uint64)]
 
 
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint64, C.c_uint64)
 _vp, _i = C.c_void_p, C.c_int
 _SIGS = {
     "hm_selfplay_config_default": (None, [C.POINTER(SelfPlayConfig)]),
     "hm_selfplay_create": (_i, [C.POINTER(SelfPlayConfig), C.POINTER(SearchConfig), C.POINTER(EvalIO), EVAL_FN, _vp, C.POINTER(_vp)]),
     "hm_selfplay_run": (_i, [_vp, C.POINTER(SelfPlayResult)]),
+    "hm_selfplay_set_chunk_sink": (_i, [_vp, CHUNK_FN, _vp]),
+    "hm_selfplay_set_output_directory": (_i, [_vp, C.c_char_p]),
     "hm_selfplay_records": (C.c_uint64, [_vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]),
     "hm_selfplay_destroy": (_i, [_vp]),
     "hm_hvm4_write_chunk": (_i, [C.c_char_p, _vp, C.c_uint64, C.c_uint64]),
@@ -67,7 +71,11 @@ def default_selfplay_config(**kw) -> SelfPlayConfig:
 class SelfPlay:
     """One rank's self-play worker.  `net(planes[rows]) -> (value, pi_a, pi_b, wdl, moves_left)` fp16."""
 
-    def __init__(self, config: SelfPlayConfig, net, search_config: SearchConfig = None, device=None):
+    def __init__(self, config: SelfPlayConfig, net, search_config: SearchConfig = None, device=None,
+                 output_directory: str = None, chunk_sink=None):
+        """output_directory: ChunkWriter (selfplay.cc:69-158) writing <dir>/training_data/chunk_<runId>_<idx>.hvm every
+        config.chunk_samples samples; chunk_sink(records uint8 array, count, chunk_index): caller's sink instead (e.g. a
+        per-chunk gather).  With neither, records stay in memory until records()."""
         from . import _require_init
         _require_init()
         self.cfg = config
@@ -120,6 +128,19 @@ class SelfPlay:
         self.h = _vp()
         scfg = search_config or default_config()
         check(lib.hm_selfplay_create(C.byref(config), C.byref(scfg), C.byref(self.io), self._cb, None, C.byref(self.h)))
+        self._sink = None
+        if chunk_sink is not None:
+            def sink(_user, data, nbytes, count, index):
+                try:
+                    chunk_sink(np.ctypeslib.as_array(data, shape=(nbytes,)).copy(), int(count), int(index))
+                    return 0
+                except Exception as e:
+                    self._error = e
+                    return 1
+            self._sink = CHUNK_FN(sink)
+            check(lib.hm_selfplay_set_chunk_sink(self.h, self._sink, None))
+        elif output_directory is not None:
+            check(lib.hm_selfplay_set_output_directory(self.h, str(output_directory).encode()))
 
     def run(self) -> SelfPlayResult:
         res = SelfPlayResult()
@@ -154,25 +175,28 @@ def write_chunk(path: str, records: np.ndarray, count: int):
 
 
 def gather_records(records: np.ndarray, count: int, dist=None):
-    """The one cross-GPU exchange: variable-length gather of finished HVM4 sample bytes to rank 0
-    (all_gather of sizes, then padded all_gather of payloads over RCCL)."""
+    """The one cross-GPU exchange: variable-length gather of finished HVM4 sample bytes to rank 0.  An all_gather of
+    (byte count, sample count) pairs, then every other rank sends exactly its payload to rank 0 (point-to-point over
+    RCCL / gloo): nothing is padded and no rank other than 0 receives anything."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return records, count
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     meta = torch.tensor([records.size, count], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
     sizes = [int(m[0]) for m in metas]
-    mx = max(max(sizes), 1)
-    pay = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    pay[:records.size] = torch.from_numpy(records).to(dev)
-    pays = [torch.zeros_like(pay) for _ in range(world)]
-    dist.all_gather(pays, pay)
-    if dist.get_rank() != 0:
+    if rank != 0:
+        if records.size:
+            dist.send(torch.from_numpy(np.ascontiguousarray(records)).to(dev), dst=0)
         return np.zeros(0, np.uint8), 0
-    out = np.concatenate([p[:s].cpu().numpy() for p, s in zip(pays, sizes)])
-    return out, sum(int(m[1]) for m in metas)
+    parts = [np.ascontiguousarray(records)]
+    for r in range(1, world):
+        if sizes[r]:
+            buf = torch.empty(sizes[r], dtype=torch.uint8, device=dev)
+            dist.recv(buf, src=r)
+            parts.append(buf.cpu().numpy())
+    return np.concatenate(parts), sum(int(m[1]) for m in metas)
 
 
 def read_hvm4(path: str):

@@ -310,13 +310,26 @@ typedef struct hm_selfplay_result {
     /* wall-clock split of `seconds`: lockstep search loop, search prologue (hm_sp_begin_search), raw-policy plies;
      * the remainder is host bookkeeping (terminal checks, record building, root statistics) */
     double   search_seconds, prologue_seconds, raw_seconds;
+    uint64_t chunks_flushed;             /* chunks handed to the sink / written to the output directory */
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,
                        hm_eval_fn fn, void* user, hm_selfplay** out);
+/* ChunkWriter (selfplay.cc:69-158).  With a sink, finished samples leave the driver every `chunk_samples` samples
+ * (ChunkWriter::append :78-85) and once more at the end of hm_selfplay_run — also when the run fails, so the games
+ * finished before an error are not lost (ChunkWriter::finish :87-91) — and host memory stays bounded by one chunk.
+ *   hm_selfplay_set_output_directory: built-in sink writing <dir>/training_data/chunk_<runId>_<index 6 digits>.hvm
+ *                                     (published atomically via .tmp + rename), the reference's file naming;
+ *   hm_selfplay_set_chunk_sink:       caller's sink (e.g. the per-chunk gather to rank 0); `records` is valid during the
+ *                                     call only; a non-zero return fails the run with HM_ERR_STATE after the remaining
+ *                                     chunks were offered.
+ * Without either, every sample stays in memory until hm_selfplay_records (tests, single-shot benchmarks). */
+typedef int (*hm_chunk_fn)(void* user, const uint8_t* records, uint64_t nbytes, uint64_t count, uint64_t chunk_index);
+int hm_selfplay_set_chunk_sink(hm_selfplay* sp, hm_chunk_fn fn, void* user);
+int hm_selfplay_set_output_directory(hm_selfplay* sp, const char* dir);
 int hm_selfplay_run(hm_selfplay* sp, hm_selfplay_result* out);
-/* Serialized TrainingSample records of the finished games (HVM4 sample layout, selfplay.cc:126-142);
- * returns the byte count; pointers stay valid until destroy. */
+/* Serialized TrainingSample records of the finished games that no sink has taken (HVM4 sample layout,
+ * selfplay.cc:126-142); returns the byte count; pointers stay valid until the next run / destroy. */
 uint64_t hm_selfplay_records(hm_selfplay* sp, const uint8_t** data, uint64_t* count);
 int hm_selfplay_destroy(hm_selfplay* sp);
 /* ChunkWriter::flush (selfplay.cc:105-151): header 'HVM4' u32 4, u16 74, u16 4672, u64 count + samples,

@@ -143,24 +143,53 @@ def test_perft_from_midgame_matches_oracle(hm):
 def test_perft5_structure_sampled(hm):
     """perft(5) from the dual start position cannot be recomputed on a CPU (3.7 core-days).
     Evidence instead: (i) the same kernels give the reference's perft(1..4) exactly (above);
-    (ii) sampled sub-trees: perft(2) below 200 random depth-3 joint positions (the leaf kernel's actual
-    work items for depth 5) equals the oracle's count for each of them."""
+    (ii) 1 000 sampled sub-trees: perft(2) below random depth-3 joint positions — the leaf kernel's actual
+    work items for depth 5 — equals the oracle's count for every one of them;
+    (iii) the same samples give Knuth's unbiased estimate of perft(5) on the CPU alone (path weight = product of the
+    branching factors): the GPU total must lie within 5 standard errors of it;
+    (iv) checksum of checksums: the perft(4) counts below the 400 depth-1 children add up to perft(5)."""
     rng = np.random.RandomState(2024)
     b = O.Board()
-    roots = []
-    while len(roots) < 200:
+    roots, weights = [], []
+    while len(roots) < 1000:
         b2 = O.Board()
-        ok = True
+        w = 1.0
         for _ in range(3):
             la, lb = b2.legal_moves(0), b2.legal_moves(1)
-            if len(la) == 0 or len(lb) == 0:
-                ok = False
+            w *= len(la) * len(lb)
+            if w == 0:
                 break
             b2.make_moves(la[rng.randint(len(la))], lb[rng.randint(len(lb))])
-        if ok:
-            roots.append(b2.compact(0, False)[0])
+        weights.append(w)
+        roots.append(b2.compact(0, False)[0])
     roots = np.array(roots, dtype=O.BOARD_DTYPE)
+    est = np.zeros(len(roots))
     for i in range(len(roots)):
+        if weights[i] == 0:
+            continue
         b.from_compact(roots[i:i + 1])
-        assert hm.perft(2, root=roots[i:i + 1])[0] == int(O.lib.ora_perft_fast(b.h, 2)), i
-    assert hm.perft(5)[0] == 24412113569071        # value first measured in round 1; pinned as a regression check
+        want = int(O.lib.ora_perft_fast(b.h, 2))
+        assert hm.perft(2, root=roots[i:i + 1])[0] == want, i
+        est[i] = weights[i] * want
+    total = hm.perft(5)[0]
+    mean, se = est.mean(), est.std(ddof=1) / np.sqrt(len(est))
+    assert abs(total - mean) < 5 * se and se / mean < 0.05, (total, mean, se)
+    kids = []
+    start = O.Board()
+    for ma in start.legal_moves(0):
+        for mb in start.legal_moves(1):
+            c = O.Board()
+            c.make_moves(ma, mb)
+            kids.append(c.compact(0, False)[0])
+    assert len(kids) == 400
+    assert sum(hm.perft(4, root=np.array([k], dtype=O.BOARD_DTYPE))[0] for k in kids) == total
+    assert total == 24412113569071                  # value first measured in round 1; kept as a regression check
+
+
+def test_plane_layout_facts_on_gpu(hm):
+    """The reference's representation tests (tests/test_representation.py:9-137, tests/golden/plane_layout_cases.json) on the HIP encoder."""
+    import test_oracle_golden as TG
+    for case in TG.LAYOUT:
+        b = TG.layout_board(case)
+        p = hm.board_to_planes(hm.to_device(b.compact(case["team"], False)), "f32").cpu().numpy().reshape(74, 64)
+        TG.check_layout(p, case)

@@ -87,3 +87,43 @@ def test_selfplay_rejects_bad_config(hm):
         hm.SelfPlay(hm.default_selfplay_config(games=0), net)
     with pytest.raises(hm.HivemindError, match="Invalid self-play exploration configuration"):
         hm.SelfPlay(hm.default_selfplay_config(node_random_factor=1.5), net)
+
+
+def test_selfplay_chunk_flushing(hm, tmp_path):
+    """ChunkWriter (selfplay.cc:69-158): with chunk_samples below the run's sample count the samples leave in chunks of exactly
+    chunk_samples (+ one remainder), named chunk_<runId>_<idx 6 digits>.hvm, and their concatenation equals the unchunked run."""
+    import glob
+    import os
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    net = N.FusedNet(N.rise_v3_small())
+    kw = dict(games=6, nodes=32, seed=21, concurrent_games=6, max_macro_plies=40)
+    res0, rec0, cnt0 = _run(hm, net, **kw)
+    assert cnt0 > 20
+    # built-in directory sink
+    sp = hm.SelfPlay(hm.default_selfplay_config(chunk_samples=16, **kw), net, output_directory=str(tmp_path / "out"))
+    res = sp.run()
+    rec, cnt = sp.records()
+    sp.close()
+    assert cnt == 0 and rec.size == 0 and res.samples == cnt0 and res.chunks_flushed == (cnt0 + 15) // 16
+    files = sorted(glob.glob(str(tmp_path / "out" / "training_data" / "chunk_21_*.hvm")))
+    assert [os.path.basename(f) for f in files] == [f"chunk_21_{i:06d}.hvm" for i in range(res.chunks_flushed)]
+    assert not glob.glob(str(tmp_path / "out" / "training_data" / "*.tmp"))
+    samples = [hm.read_hvm4(f) for f in files]
+    assert [len(x) for x in samples[:-1]] == [16] * (len(files) - 1) and 1 <= len(samples[-1]) <= 16
+    body = b"".join(open(f, "rb").read()[24:] for f in files)
+    assert body == rec0.tobytes()                                  # same samples, same order, chunk boundaries only
+    # caller's sink (what a per-chunk gather hooks into)
+    got = []
+    sp = hm.SelfPlay(hm.default_selfplay_config(chunk_samples=10, **kw), net, chunk_sink=lambda r, c, i: got.append((r.tobytes(), c, i)))
+    sp.run()
+    sp.close()
+    assert [c for _, c, _ in got][:-1] == [10] * (len(got) - 1) and [i for _, _, i in got] == list(range(len(got)))
+    assert b"".join(r for r, _, _ in got) == rec0.tobytes()
+    # a failing sink fails the run, after every chunk was offered
+    def bad(r, c, i):
+        raise RuntimeError("disk full")
+    sp = hm.SelfPlay(hm.default_selfplay_config(chunk_samples=10, **kw), net, chunk_sink=bad)
+    with pytest.raises(RuntimeError, match="disk full"):
+        sp.run()
+    sp.close()

@@ -80,6 +80,14 @@ if rank == 0:
     assert cnt == 7 and out.size == 2500 and np.all(out[:1000] == 1) and np.all(out[1000:] == 2), (cnt, out.size)
 else:
     assert cnt == 0 and out.size == 0
+# chunk boundaries: a rank with nothing to send at this boundary, then the reverse
+for turn in range(2):
+    mine = np.full(300, 7 + rank, np.uint8) if rank == turn else np.zeros(0, np.uint8)
+    out, cnt = gather_records(mine, len(mine) // 100, dist)
+    if rank == 0:
+        assert cnt == 3 and out.size == 300 and np.all(out == 7 + turn), (turn, cnt, out.size)
+    else:
+        assert cnt == 0 and out.size == 0
 dist.destroy_process_group()
 print("ok", rank)
 """
