@@ -52,9 +52,23 @@ _SIGS = {
     "hm_count_moves": (_i, [_vp, _sz, _vp, _vp]),
     "hm_make_moves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "hm_perft": (_i, [_vp, _i, _i, _i, _u64p, C.POINTER(C.c_double)]),
-    "hm_net_forward": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hm_net_forward_groups": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hm_net_profile": (_i, [_vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_create": (_i, [_vp, _sz, _vp, _vp, C.POINTER(_vp)]),
+    "hm_net_create_host": (_i, [_vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
+    "hm_net_destroy": (_i, [_vp]),
+    "hm_net_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_forward_groups": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_profile": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_save_file": (_i, [C.c_char_p, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "hm_engine_create": (_i, [_i, _i, C.POINTER(_vp)]),
+    "hm_engine_destroy": (_i, [_vp]),
+    "hm_engine_load_network": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "hm_engine_load_network_file": (_i, [_vp, C.c_char_p]),
+    "hm_engine_enqueue_half": (_i, [_vp, _vp, _sz]),
+    "hm_engine_sync_half": (_i, [_vp, _vp, _sz]),
+    "hm_engine_run_half": (_i, [_vp, _vp, _vp, _sz]),
+    "hm_engine_run_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "hm_engine_batch_size": (_i, [_vp]),
+    "hm_engine_net": (_vp, [_vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)      # AttributeError here = header/library mismatch

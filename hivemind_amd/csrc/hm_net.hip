@@ -443,90 +443,127 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
 
 }  // namespace hmn
 
-extern "C" {
-static int net_forward_impl(const int32_t*, size_t, const void*, const void*, const void*, int, const int32_t*, int, void*, void*, void*, void*, void*, void*, unsigned long long*);
+// One loaded network: descriptor on the device, launch geometry resolved once.  Re-entrant per handle; no global state.
+struct hm_net {
+    hmn::NetDesc nd;
+    hmn::NetDesc* d_nd = nullptr;
+    const void* d_wh = nullptr;
+    const void* d_wf = nullptr;
+    void* owned[2] = {nullptr, nullptr};     // parameter buffers this handle allocated (hm_net_create_host), else caller-owned
+    size_t lds = 0, stage = 0;
+    bool k5 = false;
+    int maxBlocks = 1024;
+};
 
-// desc: hmn::NetDesc as a flat int32 array (see hivemind_amd/net.py FusedNet); wh / wf: packed fp16 /
-// fp32 parameter buffers (device); planes: fp16 [n,74,8,8]; heads as in hm_sp_process.
-static int net_forward_impl(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
-                            const int32_t* d_group_rows, int group, void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream,
-                            unsigned long long* d_dbg) {
+template <typename K>
+static hipError_t launch_forward(K kern, const hm_net* net, int grid, hipStream_t st, const void* d_planes, int n, void* d_value, void* d_pi_a,
+                                 void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg) {
     using namespace hmn;
-    if (!desc || desc_ints * 4 != sizeof(NetDesc)) return hm_fail(HM_ERR_INVALID, "bad network descriptor size");
-    if (n <= 0) return 0;
-    if (d_group_rows && group <= 0) return hm_fail(HM_ERR_INVALID, "group size must be positive");
-    NetDesc nd;
-    memcpy(&nd, desc, sizeof nd);
-    if (nd.C % 64 || nd.nblocks > MAXB || nd.cv > 32) return hm_fail(HM_ERR_INVALID, "unsupported network geometry");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), net->lds, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),
+                       static_cast<const h16*>(d_planes), n, (int)net->stage, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
+                       static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
+                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
+    return hipGetLastError();
+}
+// applies `f` to the kernel instantiation this network runs on
+template <typename F>
+static hipError_t with_kernel(const hm_net* net, F f) {
+    using namespace hmn;
+    switch (net->nd.C / 64) {
+        case 1: return net->k5 ? f(rise_forward_kernel<1, true>) : f(rise_forward_kernel<1, false>);
+        case 2: return net->k5 ? f(rise_forward_kernel<2, true>) : f(rise_forward_kernel<2, false>);
+        case 4: return net->k5 ? f(rise_forward_kernel<4, true>) : f(rise_forward_kernel<4, false>);
+        case 6: return net->k5 ? f(rise_forward_kernel<6, true>) : f(rise_forward_kernel<6, false>);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" {
+
+// desc: hmn::NetDesc as a flat int32 array (see hivemind_amd/net.py FusedNet); d_wh / d_wf: packed fp16 / fp32 parameter
+// buffers on the device, caller-owned, must outlive the handle.
+int hm_net_create(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, hm_net** out) {
+    using namespace hmn;
+    if (!desc || !d_wh || !d_wf || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (desc_ints * 4 != sizeof(NetDesc)) return hm_fail(HM_ERR_INVALID, "bad network descriptor size");
+    hm_net* net = new hm_net();
+    memcpy(&net->nd, desc, sizeof(NetDesc));
+    const NetDesc& nd = net->nd;
+    auto bad = [&](const char* m) { delete net; return hm_fail(HM_ERR_INVALID, m); };
+    if (nd.C % 64 || nd.nblocks > MAXB || nd.nblocks < 0 || nd.cv > 32) return bad("unsupported network geometry");
+    if (nd.C != 64 && nd.C != 128 && nd.C != 256 && nd.C != 384) return bad("trunk width must be 64, 128, 256 or 384");
     const size_t ldx = nd.C + 8;
     size_t lds = (2 * 65 * ldx + 64 * 66 + 64 * 72) * 2 + 2 * nd.C * 4;
-    if (lds > 160 * 1024) return hm_fail(HM_ERR_INVALID, "network too wide for one LDS tile");
+    if (lds > 160 * 1024) return bad("network too wide for one LDS tile");
     size_t stage = 0;
     for (int i = 0; i < nd.nblocks; ++i) {
+        if (nd.blk[i].k != 3 && nd.blk[i].k != 5) return bad("depthwise kernel must be 3 or 5");
+        net->k5 |= nd.blk[i].k == 5;
         const size_t need = (size_t)nd.blk[i].cop * 8 + (size_t)nd.C * 4 + (size_t)nd.blk[i].cop * nd.blk[i].k * nd.blk[i].k * 2;
         if (need > stage) stage = need;
     }
     stage = (stage + 15) & ~(size_t)15;
     if (lds + stage <= 80 * 1024) lds += stage; else stage = 0;     // only while two workgroups still fit per CU
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // device copies of the descriptor: a small ring, re-uploaded (stream-ordered) only when the content changes
-    static NetDesc* d_ring = nullptr;
-    static NetDesc h_ring[8];
-    static int ring_used = 0;
-    if (!d_ring && hipMalloc(&d_ring, sizeof(NetDesc) * 8) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed");
-    int slot = -1;
-    for (int i = 0; i < ring_used; ++i) if (!memcmp(&h_ring[i], &nd, sizeof nd)) { slot = i; break; }
-    if (slot < 0) {
-        if (ring_used == 8) return hm_fail(HM_ERR_OVERFLOW, "more than 8 distinct networks in one process");
-        slot = ring_used++;
-        h_ring[slot] = nd;
-        if (hipMemcpy(d_ring + slot, &nd, sizeof nd, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "descriptor upload failed");
+    net->lds = lds; net->stage = stage;
+    net->d_wh = d_wh; net->d_wf = d_wf;
+    if (const char* e = std::getenv("HM_NET_MAX_BLOCKS")) net->maxBlocks = std::atoi(e) > 0 ? std::atoi(e) : 1024;
+    if (hipMalloc(&net->d_nd, sizeof(NetDesc)) != hipSuccess) { delete net; return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(net->d_nd, &net->nd, sizeof(NetDesc), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = with_kernel(net, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (e != hipSuccess) { (void)hipFree(net->d_nd); delete net; return hm_fail(HM_ERR_NO_DEVICE, std::string("hm_net_create: ") + hipGetErrorString(e)); }
+    *out = net;
+    return 0;
+}
+// As hm_net_create with the packed parameters in host memory: the handle uploads and owns device copies.
+int hm_net_create_host(const int32_t* desc, size_t desc_ints, const void* h_wh, size_t wh_bytes, const void* h_wf, size_t wf_bytes, hm_net** out) {
+    if (!h_wh || !h_wf || !wh_bytes || !wf_bytes || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    void *dh = nullptr, *df = nullptr;
+    if (hipMalloc(&dh, wh_bytes) != hipSuccess || hipMalloc(&df, wf_bytes) != hipSuccess) { if (dh) (void)hipFree(dh); return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed"); }
+    if (hipMemcpy(dh, h_wh, wh_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(df, h_wf, wf_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dh); (void)hipFree(df);
+        return hm_fail(HM_ERR_NO_DEVICE, "parameter upload failed");
     }
-    const NetDesc* d_nd = d_ring + slot;
-    static const int maxBlocks = std::getenv("HM_NET_MAX_BLOCKS") ? std::atoi(std::getenv("HM_NET_MAX_BLOCKS")) : 1024;
-    const int grid = n < maxBlocks ? n : maxBlocks;
-    auto args = [&](auto kern) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, d_nd, static_cast<const h16*>(d_wh), static_cast<const float*>(d_wf),
-                           static_cast<const h16*>(d_planes), n, (int)stage, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
-                           static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
-                           reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
-        return hipGetLastError();
-    };
-    bool k5 = false;
-    for (int i = 0; i < nd.nblocks; ++i) {
-        if (nd.blk[i].k != 3 && nd.blk[i].k != 5) return hm_fail(HM_ERR_INVALID, "depthwise kernel must be 3 or 5");
-        k5 |= nd.blk[i].k == 5;
-    }
-    hipError_t e;
-    switch (nd.C / 64) {
-        case 1: e = k5 ? args(rise_forward_kernel<1, true>) : args(rise_forward_kernel<1, false>); break;
-        case 2: e = k5 ? args(rise_forward_kernel<2, true>) : args(rise_forward_kernel<2, false>); break;
-        case 4: e = k5 ? args(rise_forward_kernel<4, true>) : args(rise_forward_kernel<4, false>); break;
-        case 6: e = k5 ? args(rise_forward_kernel<6, true>) : args(rise_forward_kernel<6, false>); break;
-        default: return hm_fail(HM_ERR_INVALID, "trunk width must be 64, 128, 256 or 384");
-    }
+    if (int rc = hm_net_create(desc, desc_ints, dh, df, out)) { (void)hipFree(dh); (void)hipFree(df); return rc; }
+    (*out)->owned[0] = dh; (*out)->owned[1] = df;
+    return 0;
+}
+int hm_net_destroy(hm_net* net) {
+    if (!net) return 0;
+    if (net->d_nd) (void)hipFree(net->d_nd);
+    for (void* p : net->owned) if (p) (void)hipFree(p);
+    delete net;
+    return 0;
+}
+
+static int net_forward_impl(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group, void* d_value, void* d_pi_a,
+                            void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, unsigned long long* d_dbg) {
+    if (!net || !d_planes || !d_value || !d_pi_a || !d_pi_b || !d_wdl || !d_moves_left) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (n <= 0) return 0;
+    if (d_group_rows && group <= 0) return hm_fail(HM_ERR_INVALID, "group size must be positive");
+    const int grid = n < net->maxBlocks ? n : net->maxBlocks;
+    const hipError_t e = with_kernel(net, [&](auto kern) {
+        return launch_forward(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
+    });
     if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));
     return 0;
 }
 
-int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+int hm_net_forward(const hm_net* net, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
-    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+    return net_forward_impl(net, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
 }
 // Ragged batches: rows are grouped (`group` consecutive rows per game slot) and only the first d_group_rows[g]
 // rows of group g hold a position; the other rows are skipped and their head outputs are left untouched
 // (the reference hands TensorRT exactly batchSize rows per search thread, searchthread.cc:474-484).
-int hm_net_forward_groups(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
-                          const int32_t* d_group_rows, int group,
+int hm_net_forward_groups(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
                           void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
-    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, d_group_rows, group, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+    return net_forward_impl(net, d_planes, n, d_group_rows, group, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
 }
 // diagnostic build of the same launch: d_stamps[256] receives s_memtime at the phase boundaries of workgroup 0
-int hm_net_profile(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+int hm_net_profile(const hm_net* net, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_stamps) {
-    return net_forward_impl(desc, desc_ints, d_wh, d_wf, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream,
+    return net_forward_impl(net, d_planes, n, nullptr, 0, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream,
                             reinterpret_cast<unsigned long long*>(d_stamps));
 }
 

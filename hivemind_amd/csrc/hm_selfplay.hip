@@ -202,9 +202,8 @@ static void finish_game(hm_selfplay* s, Slot& sl) {   // selfplay.cc:726-734
 }
 
 static int eval_rows_sync(hm_selfplay* s, int which, int rows) {   // evaluator on the null stream (raw-policy plies, callback mode)
-    if (s->io.net_desc)
-        return hm_net_forward(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], rows,
-                              s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr);
+    if (s->io.net)
+        return hm_net_forward(s->io.net, s->io.planes[which], rows, s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left, nullptr);
     if (int rc = s->fn(s->user, which, rows)) return hm_fail(HM_ERR_STATE, "evaluator callback failed (" + std::to_string(rc) + ")");
     return 0;
 }
@@ -212,7 +211,7 @@ static int eval_rows_sync(hm_selfplay* s, int which, int rows) {   // evaluator 
 static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     constexpr int RING = 256;
     int which = 0, active = 1, iters = 0;
-    const bool native = s->io.net_desc != nullptr;
+    const bool native = s->io.net != nullptr;
     if (s->evs.empty()) {
         s->evs.resize((size_t)RING * 6);
         for (auto& e : s->evs) if (hipEventCreate(&e) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipEventCreate failed");
@@ -284,8 +283,8 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             // forward is ordered behind process(i-1) and overlaps only collect(i).
             if (iters > 0) (void)hipStreamWaitEvent(s->sN, yPrev[1], 0);
             if (timed) (void)hipEventRecord(e[2], s->sN);
-            if (int rc = hm_net_forward_groups(s->io.net_desc, s->io.net_desc_ints, s->io.net_wh, s->io.net_wf, s->io.planes[which], s->G * 8,
-                                               allRows ? nullptr : s->d_rows[which], 8, h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+            if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8,
+                                               h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
             if (timed) (void)hipEventRecord(e[3], s->sN);
             (void)hipEventRecord(y[0], s->sN);
             (void)hipStreamWaitEvent(s->sT, y[0], 0);
@@ -333,8 +332,8 @@ void hm_selfplay_config_default(hm_selfplay_config* c) {   // tools/selfplay.h:1
 }
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* scfg, const hm_eval_io* io, hm_eval_fn fn, void* user, hm_selfplay** out) {
-    if (!cfg || !io || (!fn && !io->net_desc) || !out) return hm_fail(HM_ERR_INVALID, "null argument");
-    if (io->net_desc && (!io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2))
+    if (!cfg || !io || (!fn && !io->net) || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (io->net && (!io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2))
         return hm_fail(HM_ERR_INVALID, "native evaluator needs the second set of head buffers");
     const hm_selfplay_config& c = *cfg;
     if (c.games == 0 || c.nodes == 0 || c.max_macro_plies == 0) return hm_fail(HM_ERR_INVALID, "games, nodes, and max-macro-plies must be positive");

@@ -136,6 +136,29 @@ def rise_v3_small() -> RiseV3:
     return RiseV3(128, 128, 32, [3] * 6, [False, False, False, False, True, True], 8, 256)
 
 
+def load_checkpoint(path, model: RiseV3 = None, map_location="cpu") -> RiseV3:
+    """Trained-weight ingestion: the reference trainer's checkpoint file, written by save_torch_state
+    (src/training/trainer_agent.py:871-890) as torch.save({'model_state_dict', 'optimizer_state_dict',
+    ['training_iteration', 'evaluation_step', 'batch_steps']}) and restored by restore_torch_state (:866-868) with a strict
+    load_state_dict.  A bare state_dict is accepted too; 'module.' / '_orig_mod.' prefixes (DataParallel, torch.compile) are
+    stripped.  Returns the model in eval mode, ready for InferenceNet / FusedNet."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
+    if not isinstance(sd, dict) or not sd:
+        raise ValueError(f"{path}: no model_state_dict")
+    clean = {}
+    for k, v in sd.items():
+        for pre in ("module.", "_orig_mod."):
+            while k.startswith(pre):
+                k = k[len(pre):]
+        clean[k] = v
+    if model is None:
+        ch = clean["body_spatial.0.body.0.weight"].shape[0]
+        model = rise_v33() if ch == 384 else rise_v3_small()
+    model.load_state_dict(clean, strict=True)
+    return model.eval()
+
+
 def flops_per_position(model: RiseV3) -> float:
     """Multiply-accumulate count x2 of the conv / linear layers at 8x8."""
     total = 0
@@ -370,6 +393,27 @@ class FusedNet:
         self.wf = torch.cat(floats).to(device=device, dtype=torch.float32).contiguous()
         self.device = self.wh.device
         self._out = {}
+        h = C.c_void_p()
+        check(lib.hm_net_create(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(), C.byref(h)))
+        self.handle = h            # hm_net*: descriptor on the device, launch geometry resolved once
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.hm_net_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def save(self, path: str):
+        """Packed-network file (the plan-file counterpart Engine::loadNetwork reads back, nn/engine.cc:290-401)."""
+        wh = self.wh.cpu().numpy()
+        wf = self.wf.cpu().numpy()
+        self._check(self._lib.hm_net_save_file(str(path).encode(), self.desc.ctypes.data, self.desc.size, wh.ctypes.data, wh.nbytes,
+                                               wf.ctypes.data, wf.nbytes))
 
     def _buffers(self, n):
         if n not in self._out:
@@ -388,13 +432,11 @@ class FusedNet:
         v, a, b, w, m = out if out is not None else self._buffers(n)
         st = torch.cuda.current_stream().cuda_stream
         if group_rows is None:
-            self._check(self._lib.hm_net_forward(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
-                                                 planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),
+            self._check(self._lib.hm_net_forward(self.handle, planes.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(),
                                                  m.data_ptr(), self._C.c_void_p(st)))
         else:
             if group_rows.dtype != torch.int32 or group_rows.numel() * group != n or group_rows.device.type != "cuda":
                 raise ValueError("group_rows must be an int32 CUDA tensor with n / group entries")
-            self._check(self._lib.hm_net_forward_groups(self.desc.ctypes.data, self.desc.size, self.wh.data_ptr(), self.wf.data_ptr(),
-                                                        planes.data_ptr(), n, group_rows.data_ptr(), group, v.data_ptr(), a.data_ptr(),
+            self._check(self._lib.hm_net_forward_groups(self.handle, planes.data_ptr(), n, group_rows.data_ptr(), group, v.data_ptr(), a.data_ptr(),
                                                         b.data_ptr(), w.data_ptr(), m.data_ptr(), self._C.c_void_p(st)))
         return v, a, b, w, m

@@ -26,7 +26,7 @@ class SelfPlayConfig(C.Structure):
 class EvalIO(C.Structure):
     _fields_ = [("planes", C.c_void_p * 2), ("value", C.c_void_p), ("pi_a", C.c_void_p), ("pi_b", C.c_void_p),
                 ("wdl", C.c_void_p), ("moves_left", C.c_void_p),
-                ("net_desc", C.c_void_p), ("net_desc_ints", C.c_uint64), ("net_wh", C.c_void_p), ("net_wf", C.c_void_p),
+                ("net", C.c_void_p),
                 ("value_2", C.c_void_p), ("pi_a_2", C.c_void_p), ("pi_b_2", C.c_void_p), ("wdl_2", C.c_void_p),
                 ("moves_left_2", C.c_void_p)]
 
@@ -101,9 +101,7 @@ class SelfPlay:
             # forward runs on its own stream, overlapped with leaf collection)
             self._heads2 = (torch.zeros(rows, **f16), torch.zeros((rows, 4672), **f16), torch.zeros((rows, 4672), **f16),
                             torch.zeros((rows, 3), **f16), torch.zeros(rows, **f16))
-            self.io.net_desc = net.desc.ctypes.data
-            self.io.net_desc_ints = net.desc.size
-            self.io.net_wh, self.io.net_wf = net.wh.data_ptr(), net.wf.data_ptr()
+            self.io.net = net.handle
             (self.io.value_2, self.io.pi_a_2, self.io.pi_b_2, self.io.wdl_2, self.io.moves_left_2) = [t.data_ptr() for t in self._heads2]
 
         fused = hasattr(self.net, "wh")            # FusedNet: writes the registered head buffers directly

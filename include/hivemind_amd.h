@@ -242,23 +242,68 @@ int hm_sp_trace(unsigned long long* out, int cap);
 
 /* ================================================================== */
 /* RISEv3 forward as one kernel launch (evaluator hot op; replaces the  */
-/* TensorRT FP16 plan of nn/engine.cc:290-401,577-650).  desc = packed  */
-/* network descriptor (hivemind_amd/net.py FusedNet), d_wh / d_wf =     */
-/* fp16 / fp32 parameter buffers in MFMA fragment order, d_planes =     */
-/* fp16 [n,74,8,8]; heads as in hm_sp_process.                          */
+/* TensorRT FP16 plan of nn/engine.cc:290-401,577-650).  A network is a */
+/* handle: hm_net_create takes the packed descriptor (hivemind_amd/     */
+/* net.py FusedNet: hmn::NetDesc as int32s) and the fp16 / fp32         */
+/* parameter buffers in MFMA fragment order (device, caller-owned);     */
+/* hm_net_create_host takes them from host memory and owns the device   */
+/* copies (what Engine::loadNetwork does with a plan file).  Handles are*/
+/* independent: no process-global state.  d_planes = fp16 [n,74,8,8];   */
+/* heads as in hm_sp_process.                                           */
 /* ================================================================== */
-int hm_net_forward(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+typedef struct hm_net hm_net;
+int hm_net_create(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, hm_net** out);
+int hm_net_create_host(const int32_t* desc, size_t desc_ints, const void* h_wh, size_t wh_bytes, const void* h_wf, size_t wf_bytes, hm_net** out);
+int hm_net_destroy(hm_net* net);
+int hm_net_forward(const hm_net* net, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
 /* Ragged batch: rows come in groups of `group` (one group per game slot); only the first d_group_rows[g]
  * rows of group g are evaluated (d_group_rows from hm_sp_collect_counted), the rest are skipped. */
-int hm_net_forward_groups(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
-                          const int32_t* d_group_rows, int group,
+int hm_net_forward_groups(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
                           void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
-
 /* Diagnostic variant: same launch, d_stamps[256] (device u64) receives the shader clock at the phase
  * boundaries of workgroup 0 (tools/profile_net.py). */
-int hm_net_profile(const int32_t* desc, size_t desc_ints, const void* d_wh, const void* d_wf, const void* d_planes, int n,
+int hm_net_profile(const hm_net* net, const void* d_planes, int n,
                    void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_stamps);
+
+/* ================================================================== */
+/* Evaluator seam as an object: class Engine (nn/engine.h:43-81).       */
+/*   Engine(int deviceId, int batchSize = 8)      hm_engine_create      */
+/*   bool loadNetwork(onnxFile, engineFile)       hm_engine_load_network (packed network in memory) /           */
+/*                                                hm_engine_load_network_file (the "plan" file FusedNet.save writes) */
+/*   bool enqueueInferenceHalf(obs, worker)       hm_engine_enqueue_half */
+/*   bool synchronizeInferenceHalf(out&, worker)  hm_engine_sync_half   */
+/*   bool runInferenceHalf(obs, out&, worker)     hm_engine_run_half    */
+/*   bool runInference(float* ..., worker)        hm_engine_run_f32     */
+/*   int  getBatchSize()                          hm_engine_batch_size  */
+/* HM_ENGINE_WORKERS (= SearchParams::NUM_SEARCH_THREADS, 4) execution  */
+/* states, each with its own stream, device buffers and pinned host     */
+/* output buffers; each worker may have ONE request in flight: a second */
+/* enqueue before the sync, or a sync with nothing pending, returns     */
+/* HM_ERR_STATE (the reference returns false, engine.cc:585-590,        */
+/* 659-664).  obs: caller-owned batch x 4736 fp16, host (pinned or      */
+/* pageable) or device memory; it must stay unchanged until the sync.   */
+/* Output pointers are engine-owned pinned host memory, valid until the */
+/* next enqueue on that worker.  Output semantics as hm_sp_process.     */
+/* ================================================================== */
+#define HM_ENGINE_WORKERS 4
+typedef struct hm_engine hm_engine;
+typedef struct hm_half_outputs {          /* Engine::HalfInferenceOutputs, nn/engine.h:45-51 (fp16 bit patterns) */
+    const uint16_t* value; const uint16_t* policy_a; const uint16_t* policy_b; const uint16_t* wdl; const uint16_t* moves_left;
+} hm_half_outputs;
+int hm_engine_create(int device, int batch_size, hm_engine** out);
+int hm_engine_destroy(hm_engine* e);
+int hm_engine_load_network(hm_engine* e, const int32_t* desc, size_t desc_ints, const void* h_wh, size_t wh_bytes, const void* h_wf, size_t wf_bytes);
+int hm_engine_load_network_file(hm_engine* e, const char* path);
+int hm_engine_enqueue_half(hm_engine* e, const void* obs, size_t worker);
+int hm_engine_sync_half(hm_engine* e, hm_half_outputs* out, size_t worker);
+int hm_engine_run_half(hm_engine* e, const void* obs, hm_half_outputs* out, size_t worker);
+int hm_engine_run_f32(hm_engine* e, const float* obs, float* value, float* pi_a, float* pi_b, float* wdl, float* moves_left, size_t worker);
+int hm_engine_batch_size(const hm_engine* e);
+/* The loaded network, for callers that keep their buffers on the device (hm_eval_io.net). */
+const hm_net* hm_engine_net(const hm_engine* e);
+/* Packed-network file ("plan"): 'HMNP' u32 version=1, u64 desc_ints, u64 wh_bytes, u64 wf_bytes, then the three blobs. */
+int hm_net_save_file(const char* path, const int32_t* desc, size_t desc_ints, const void* h_wh, size_t wh_bytes, const void* h_wf, size_t wf_bytes);
 
 /* ================================================================== */
 /* self-play driver: run_selfplay (tools/selfplay.h:10-33,              */
@@ -289,10 +334,10 @@ void hm_selfplay_config_default(hm_selfplay_config* cfg);
 typedef struct hm_eval_io {
     void* planes[2];
     void* value; void* pi_a; void* pi_b; void* wdl; void* moves_left;
-    /* Optional native evaluator: when net_desc != NULL the driver calls hm_net_forward itself
+    /* Optional native evaluator: when net != NULL the driver calls hm_net_forward itself
      * (no callback) on a second stream, overlapping it with hm_sp_collect; *_2 is the second set
      * of head buffers the overlap needs. */
-    const int32_t* net_desc; uint64_t net_desc_ints; const void* net_wh; const void* net_wf;
+    const hm_net* net;
     void* value_2; void* pi_a_2; void* pi_b_2; void* wdl_2; void* moves_left_2;
 } hm_eval_io;
 /* Runs the network on the first `rows` rows of planes[which] and fills the head buffers

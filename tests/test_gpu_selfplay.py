@@ -111,7 +111,7 @@ def test_selfplay_chunk_flushing(hm, tmp_path):
     assert not glob.glob(str(tmp_path / "out" / "training_data" / "*.tmp"))
     samples = [hm.read_hvm4(f) for f in files]
     assert [len(x) for x in samples[:-1]] == [16] * (len(files) - 1) and 1 <= len(samples[-1]) <= 16
-    body = b"".join(open(f, "rb").read()[24:] for f in files)
+    body = b"".join(open(f, "rb").read()[20:] for f in files)
     assert body == rec0.tobytes()                                  # same samples, same order, chunk boundaries only
     # caller's sink (what a per-chunk gather hooks into)
     got = []
@@ -127,3 +127,34 @@ def test_selfplay_chunk_flushing(hm, tmp_path):
     with pytest.raises(RuntimeError, match="disk full"):
         sp.run()
     sp.close()
+
+
+def test_selfplay_full_network_configs3(hm, tmp_path):
+    """BASELINE configs[3] on one GPU (its 8-GPU game sharding is the record gather, tested separately and unmeasured here):
+    self-play through the deployed RISEv3.3 (15 blocks, 384 channels, 5x5 depthwise + ECA blocks) — record validity,
+    determinism, and the search inside it identical to the callback path driving the same fused network."""
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    net = N.FusedNet(N.rise_v33())
+    kw = dict(games=8, nodes=64, seed=4, concurrent_games=8, max_macro_plies=24)
+    res, rec, cnt = _run(hm, net, **kw)
+    assert res.games == 8 and cnt == res.samples > 0 and res.eval_rows > 0
+    games = _by_game(hm, tmp_path, rec, cnt, "full.hvm")
+    for ss in games.values():
+        for s in ss:
+            assert 1 <= s["nodes"] <= 64 * 1.05 + 16 and s["wdl"] == s["outcome"] + 1
+            for pol in (s["policy_a"], s["policy_b"]):
+                assert abs(float(pol["prob"].sum()) - 1.0) < 1e-4
+    _, rec2, cnt2 = _run(hm, net, **kw)
+    assert cnt2 == cnt and rec2.tobytes() == rec.tobytes()
+
+    class Callback:                  # same network behind the callback seam (no native overlap path)
+        native = False
+        wh = None
+
+        def __call__(self, planes):
+            return net(planes)
+    cb = Callback()
+    del Callback.wh
+    _, rec3, cnt3 = _run(hm, cb, **kw)
+    assert cnt3 == cnt and rec3.tobytes() == rec.tobytes()

@@ -26,7 +26,7 @@ class HashNet:
 def _split_by_game(hm, tmp_path, rec, cnt, name):
     path = str(tmp_path / name)
     hm.write_chunk(path, rec, cnt)
-    raw = open(path, "rb").read()[24:]
+    raw = open(path, "rb").read()[20:]
     # walk the records to cut per-game byte ranges
     import struct
     out, off = {}, 0

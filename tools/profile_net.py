@@ -11,8 +11,7 @@ x = torch.rand((n, 74, 8, 8), device="cuda").half()
 for _ in range(3): f(x)
 v, a, b, w, m = f._buffers(n)
 st = torch.zeros(256, dtype=torch.int64, device="cuda")
-hm.check(hm.lib.hm_net_profile(f.desc.ctypes.data, f.desc.size, f.wh.data_ptr(), f.wf.data_ptr(), x.data_ptr(), n, v.data_ptr(), a.data_ptr(),
-                               b.data_ptr(), w.data_ptr(), m.data_ptr(), None, st.data_ptr()))
+hm.check(hm.lib.hm_net_profile(f.handle, x.data_ptr(), n, v.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(), m.data_ptr(), None, st.data_ptr()))
 torch.cuda.synchronize()
 t = st.cpu().numpy()
 t = t[t > 0]
