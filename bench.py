@@ -99,17 +99,31 @@ def cpu_selfplay_baseline(model, nodes, seconds=20.0):
 
 
 def _pmc_traffic(path):
-    """bytes per launch by kernel = WRITE_SIZE + corrected FETCH_SIZE of a committed rocprofv3 PMC summary."""
-    full = os.path.join(os.path.dirname(os.path.abspath(__file__)), path)
-    out = {}
+    """bytes per launch by kernel = WRITE_SIZE + corrected FETCH_SIZE of a committed rocprofv3 PMC summary
+    (tools/pmc_summary.py; per kernel and counter the grid size with the most launches).  Refused — empty result —
+    unless the summary was taken on exactly the kernel sources this bench runs (sha256 over hivemind_amd/csrc + include):
+    counters of an older kernel say nothing about this one."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    best = {}
     try:
-        rows = json.load(open(full))
-        rows = rows["rows"] if isinstance(rows, dict) else rows
-        for r in rows:
-            out[r["kernel"]] = out.get(r["kernel"], 0.0) + float(r["avg_bytes"])
+        prof = json.load(open(os.path.join(ROOT, path)))
+        if not isinstance(prof, dict) or prof.get("source_sha256") != pmc_summary.source_hash():
+            return {}
+        for r in prof["rows"]:
+            key = (r["kernel"], r["counter"])
+            if key not in best or r["launches"] > best[key]["launches"]:
+                best[key] = r
     except (OSError, ValueError, KeyError):
-        pass
+        return {}
+    out = {}
+    for (kernel, _), r in best.items():
+        out[kernel] = out.get(kernel, 0.0) + float(r["avg_bytes"])
     return out
+
+
+PMC_SELFPLAY = "profiles/r02_selfplay64_pmc_hbm.json"
+PMC_PLANES = "profiles/r02_planes_pmc_hbm.json"
 
 
 def main():
@@ -191,7 +205,7 @@ def main():
             return res, rec, cnt
         for w in range(args.warmup):
             one_run(1000 + w)
-        tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0)
+        tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0, lw=0)
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -199,7 +213,7 @@ def main():
             tot["samples"] += res.samples; tot["nodes"] += res.total_nodes; tot["eval_rows"] += res.eval_rows
             tot["iters"] += res.search_iterations; tot["collect_ms"] += res.collect_ms; tot["eval_ms"] += res.eval_ms
             tot["process_ms"] += res.process_ms; tot["nv"] += res.nodes_visited; tot["es"] += res.edges_scanned
-            tot["games"] += res.games; tot["bytes"] += rec.size
+            tot["games"] += res.games; tot["bytes"] += rec.size; tot["lw"] += res.leaf_move_words
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         samples = sum_over_ranks(tot["samples"])
@@ -216,20 +230,23 @@ def main():
                     "traffic": None, "kernel": "RISEv3 forward (net)", "kernel_ms": net_ms,
                     "algorithmic_flops_per_launch": rows * flops, "rows_per_launch": rows}
         # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node,
-        # plus the 9472-byte fp16 plane tensor of every leaf
+        # plus, per network leaf, the 9472-byte fp16 plane tensor and its legal move lists (4 B per move, counted by the kernel)
         tree_ms = legs["k_collect (tree traversal)"]
-        by = (tot["nv"] * (64 + 104) + tot["es"] * 40) / it + rows * 9472
+        by = (tot["nv"] * (64 + 104) + tot["es"] * 40 + tot["lw"] * 4) / it + rows * 9472
         ach = by / (tree_ms * 1e-3) / 1e9
         roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_collect (tree traversal)", "kernel_ms": tree_ms, "algorithmic_bytes_per_launch": by,
                      "note": "latency-bound: one wavefront per game walks its tree with dependent loads; see DESIGN.md"}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this workload (WRITE_SIZE + 2 x FETCH_SIZE,
         # separate passes; profiles/r01_selfplay64_pmc_hbm.json) - PMC counters cannot be read from inside the bench
-        pmc = _pmc_traffic("profiles/r01_selfplay64_pmc_hbm.json")
-        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward_kernel<2,false>")):
-            if key in pmc and args.games == 64 and args.nodes == 400 and args.model == "small":
-                r_["traffic"] = pmc[key]
-                r_["traffic_source"] = "profiles/r01_selfplay64_pmc_hbm.json (rocprofv3 --pmc, same workload)"
+        pmc = _pmc_traffic(PMC_SELFPLAY) if (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
+        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward_kernel")):
+            hit = [k for k in pmc if k.startswith(key)]
+            if hit:
+                r_["traffic"] = sum(pmc[k] for k in hit)
+                r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
+            else:
+                r_["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"
         roof = roof_net if dominant.startswith("RISEv3") else roof_tree
         extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
@@ -256,7 +273,8 @@ def main():
                                                       "net_TFLOPs": r.eval_rows / it256 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
             pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
             extra["plane_encode_64k"] = pl
-            enc = _pmc_traffic("profiles/r01_bench_pmc_hbm.json").get("void encode_planes_kernel<0>")
+            enc_all = _pmc_traffic(PMC_PLANES)
+            enc = next((v for k, v in enc_all.items() if k.startswith("encode_planes_kernel<0>")), None)
             extra["rooflines"].append({"bound": "hbm", "achieved": pl["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": pl["hbm_frac"], "traffic": enc, "kernel": "encode_planes_kernel<f16>",
                                        "kernel_ms": pl["kernel_ms"], "algorithmic_bytes_per_launch": pl["algorithmic_bytes_per_launch"]})

@@ -111,6 +111,7 @@ struct Game {
     int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
     int nodesVisited, edgesScanned;     // traversal traffic counters (roofline accounting)
     int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
+    int listWords;                      // leaf move-list words written by the helper wave (traffic accounting)
     int live;                           // slot holds a game (set by k_set_games); dead slots are skipped by every kernel
 };
 
@@ -1265,7 +1266,7 @@ __device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, Wave
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) pl.leafCounts[base + b] = kept;
+        if (lane == 0) { pl.leafCounts[base + b] = kept; atomicAdd(&pl.games[g].listWords, kept); }
     }
 }
 
@@ -1334,7 +1335,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     gm.nodeCount = 0; gm.arenaTop = 1; gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
     gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
     gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
-    gm.nodesVisited = gm.edgesScanned = 0; gm.fresh = 0;
+    gm.nodesVisited = gm.edgesScanned = 0; gm.fresh = 0; gm.listWords = 0;
     gm.targetNodes = targetNodes[g]; gm.noiseSeed = noiseSeeds ? noiseSeeds[g] : 0; gm.alpha = alpha; gm.eps = eps;
     gm.root = -1;
     Path p;
@@ -1543,7 +1544,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         o.counts[g] = n; o.rootQ[g] = rq;
         int* inf = o.info + (size_t)g * HM_SP_INFO_INTS;
         inf[12] = gm.root >= 0 ? best_move_index(s, s.nodes[gm.root], prm.qVetoDelta, prm.qValueWeight) : -1;
-        inf[13] = inf[14] = inf[15] = 0;
+        inf[13] = gm.listWords; inf[14] = inf[15] = 0;
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
         inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;

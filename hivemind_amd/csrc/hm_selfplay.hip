@@ -123,6 +123,11 @@ struct hm_selfplay {
     std::vector<hipEvent_t> evs, sync;                 // ring of per-iteration leg events
     hipStream_t sT = nullptr, sN = nullptr;      // tree / network streams (native evaluator mode)
     int* hActive = nullptr;
+    // K lockstep iterations captured once as a HIP graph (collect || forward -> process, K times): one launch replays them,
+    // so the dependent launches and cross-stream waits of the inner loop cost graph edges instead of host round trips
+    hipGraphExec_t stepGraph = nullptr;
+    hipEvent_t gFork = nullptr, gJoin = nullptr;
+    int graphState = 0;                            // 0 not tried, 1 ready, -1 unavailable (eager loop)
     int32_t* d_rows[2] = {nullptr, nullptr};   // per game slot: plane rows written into planes[k] (ragged evaluator batch)
 };
 
@@ -208,6 +213,38 @@ static int eval_rows_sync(hm_selfplay* s, int which, int rows) {   // evaluator 
     return 0;
 }
 
+constexpr int GRAPH_ITERS = 8;                   // even: the plane / head double buffers are back where they started
+
+// one native lockstep iteration enqueued on (sT, sN): collect(next) on the tree stream beside forward(cur) on the network
+// stream, then process(cur) on the tree stream.  `fork`/`join` are ordering-only events.
+static int enqueue_iteration(hm_selfplay* s, int which, int parity, hipEvent_t fork, hipEvent_t join, bool allRows) {
+    void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
+                      {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
+    void** h = hv[parity];
+    (void)hipEventRecord(fork, s->sT);             // forward(i) runs behind process(i-1), beside collect(i)
+    (void)hipStreamWaitEvent(s->sN, fork, 0);
+    if (int rc = hm_sp_collect_counted(s->sp, s->io.planes[1 - which], s->d_rows[1 - which], s->sT)) return rc;
+    if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8,
+                                       h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+    (void)hipEventRecord(join, s->sN);
+    (void)hipStreamWaitEvent(s->sT, join, 0);
+    return hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT);
+}
+
+static void build_step_graph(hm_selfplay* s, bool allRows) {
+    s->graphState = -1;
+    if (std::getenv("HM_SELFPLAY_NO_GRAPH") || s->sN == s->sT) return;
+    if (hipEventCreateWithFlags(&s->gFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->gJoin, hipEventDisableTiming) != hipSuccess) return;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s->sT, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
+    int rc = 0;
+    for (int k = 0; k < GRAPH_ITERS && !rc; ++k) rc = enqueue_iteration(s, k & 1, k & 1, s->gFork, s->gJoin, allRows);
+    const hipError_t e = hipStreamEndCapture(s->sT, &graph);
+    if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return; }
+    if (hipGraphInstantiate(&s->stepGraph, graph, nullptr, nullptr, 0) == hipSuccess) s->graphState = 1;
+    (void)hipGraphDestroy(graph);
+}
+
 static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     constexpr int RING = 256;
     int which = 0, active = 1, iters = 0;
@@ -250,25 +287,43 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
     const int noPollBefore = minTarget / 8 - 1;
-    int harvested = 0;
+    // Leg timings (HIP events on the launch streams) are sampled: event records are not free.  The samples of one search
+    // are averaged and stand for all of its iterations.
+    int harvested = 0, nSamples = 0;
+    double sum[3] = {0.0, 0.0, 0.0};
+    auto is_timed = [&](int it) { return !native || (s->graphState == 1 ? (it == 3 || it == 6) : (it & 7) == 0); };
     auto harvest = [&](int upto) {                 // leg timings of the sampled iterations in [harvested, upto)
         for (int it = harvested; it < upto; ++it) {
-            if (native && (it & 7) != 0) continue;
+            if (!is_timed(it)) continue;
             hipEvent_t* e = &s->evs[(size_t)(it % RING) * 6];
             float ms = 0.0f;
-            const double w = native ? 8.0 : 1.0;   // each sample stands for 8 iterations
-            if (hipEventElapsedTime(&ms, e[0], e[1]) == hipSuccess) s->res.collect_ms += w * ms;
-            if (hipEventElapsedTime(&ms, e[2], e[3]) == hipSuccess) s->res.eval_ms += w * ms;
-            if (hipEventElapsedTime(&ms, e[4], e[5]) == hipSuccess) s->res.process_ms += w * ms;
+            bool ok = true;
+            double v[3];
+            for (int k = 0; k < 3; ++k) { ok = ok && hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1]) == hipSuccess; v[k] = ms; }
+            if (ok) { for (int k = 0; k < 3; ++k) sum[k] += v[k]; ++nSamples; }
         }
         harvested = upto;
     };
+    if (native && s->graphState == 0) build_step_graph(s, allRows);
     while (active > 0) {
+        // Leg timings are sampled on eager iterations (the first GRAPH_ITERS of every search); after that the loop replays the
+        // captured graph, GRAPH_ITERS iterations per launch, polling the active-game count once per launch.
+        if (native && s->graphState == 1 && iters >= GRAPH_ITERS && which == 0) {
+            if (hipGraphLaunch(s->stepGraph, s->sT) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipGraphLaunch failed");
+            iters += GRAPH_ITERS;
+            s->res.eval_batches += GRAPH_ITERS;
+            if (iters >= noPollBefore) {
+                if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;
+                active = *s->hActive;
+            }
+            if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
+            continue;
+        }
         hipEvent_t* e = &s->evs[(size_t)(iters % RING) * 6];
         hipEvent_t* y = &s->sync[(size_t)(iters % RING) * 2];
         hipEvent_t* yPrev = &s->sync[(size_t)((iters + RING - 1) % RING) * 2];
         const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
-        const bool timed = (iters & 7) == 0;       // leg timing is sampled: event records are not free
+        const bool timed = is_timed(iters);
         if (native) {
             // tree stream: collect(next) -- net stream: forward(cur) -- tree stream: process(cur)
             void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
@@ -311,8 +366,13 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         which = 1 - which;
         s->res.eval_batches += 1;
         ++iters;
-        if (poll) harvest(iters);
+        if (poll && !(native && s->graphState == 1)) harvest(iters);
         if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
+    }
+    harvest(std::min(iters, s->graphState == 1 && native ? GRAPH_ITERS : iters));      // the stream was synchronised by the last poll
+    if (nSamples > 0) {
+        const double w = (double)iters / nSamples;
+        s->res.collect_ms += w * sum[0]; s->res.eval_ms += w * sum[1]; s->res.process_ms += w * sum[2];
     }
     s->res.search_iterations += iters;
     return 0;
@@ -369,6 +429,9 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->sT) (void)hipStreamDestroy(s->sT);
     if (s->sN && s->sN != s->sT) (void)hipStreamDestroy(s->sN);
     if (s->hActive) (void)hipHostFree(s->hActive);
+    if (s->stepGraph) (void)hipGraphExecDestroy(s->stepGraph);
+    if (s->gFork) (void)hipEventDestroy(s->gFork);
+    if (s->gJoin) (void)hipEventDestroy(s->gJoin);
     for (auto& e : s->evs) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->sync) if (e) (void)hipEventDestroy(e);
     delete s;
@@ -562,6 +625,7 @@ static int selfplay_run_impl(hm_selfplay* s) {
             s->res.eval_rows += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 2];
             s->res.nodes_visited += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 10];
             s->res.edges_scanned += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 11];
+            s->res.leaf_move_words += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 13];
             const int n = counts[g];
             if (n == 0) { sl.winner = sl.team == HM_WHITE ? 1 : 0; sl.termination = 4; finish_game(s, sl); continue; }
             const hm_move* ea = mA.data() + (size_t)g * E;

@@ -206,7 +206,8 @@ int hm_sp_active(hm_sp* sp, int* active);
  * reservation collisions, node count, root type, root visits, overflow flags, max depth,
  * tree nodes visited and edges scanned during selection (traffic accounting), [12] = index of the
  * joint action Agent::run_search returns (get_best_move_idx_with_q_weight, node.h:656-754 with
- * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13..15] reserved. */
+ * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13] = leaf move-list words written
+ * (traffic accounting), [14..15] reserved. */
 #define HM_SP_INFO_INTS 16
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
@@ -356,6 +357,7 @@ typedef struct hm_selfplay_result {
      * the remainder is host bookkeeping (terminal checks, record building, root statistics) */
     double   search_seconds, prologue_seconds, raw_seconds;
     uint64_t chunks_flushed;             /* chunks handed to the sink / written to the output directory */
+    uint64_t leaf_move_words;            /* 4-byte move-list entries the traversal wrote for its network leaves (roofline accounting) */
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,
