@@ -17,6 +17,7 @@
 // MFMA issue + LDS fragment reads (M = 64 rows per workgroup), not by HBM.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -205,8 +206,12 @@ __device__ __forceinline__ void depthwise_rows(const h16* y1 /*[66] row of this 
     }
 }
 
-template <int CT, bool K5>      // CT = C / 64 accumulator tiles per wave; K5 = some block uses a 5x5 depthwise
-__global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
+// CT = C / 64 accumulator tiles per wave; K5 = some block uses a 5x5 depthwise; OCC = workgroups the register budget must
+// leave room for per CU.  The search hands over a few hundred rows at a time — at most one workgroup per CU — so the
+// narrow nets also come in an OCC = 1 form that may use the whole register file (the OCC = 2 form of <2,*> spills ~100
+// VGPRs per lane to scratch, 57 MB of scratch writes per launch in the round-1 PMC profile); large batches keep OCC = 2.
+template <int CT, bool K5, int OCC>
+__global__ __launch_bounds__(256, OCC) void rise_forward_kernel(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
                                                            const h16* __restrict__ planes, int n, int stageBytes,
                                                            h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
                                                            h16* __restrict__ wdl, h16* __restrict__ ml,
@@ -441,6 +446,333 @@ __global__ __launch_bounds__(256, (CT <= 2 ? 2 : 1)) void rise_forward_kernel(co
 #undef HM_STAMP
 }
 
+
+// =============================================================================================================
+// Narrow trunks (C <= 128, the self-play "RISEv3-small"): a latency-first form of the same fused forward.
+//
+// The search hands the evaluator a few hundred positions at a time — at most one workgroup per CU — so what the lockstep
+// loop waits for is the latency of ONE position through the network, not throughput.  The 4-wave kernel above walks a
+// mobile block in 64-channel chunks (three barriers and three exposed weight-fetch latencies per chunk: 63 barriers for
+// the small net, 153 us per position).  Here one position gets 8 waves (512 threads), every wave owns exactly one 32x32
+// tile of an N = C GEMM, a block is three phases over ALL its expanded channels (expand -> depthwise -> project), and each
+// GEMM keeps PF weight fragments (1 KiB wave-loads straight from L2) in flight, the first ones issued before the barrier
+// that opens the phase.  im2col row offsets are computed once per convolution, not per k-step.
+// LDS: Xs[65][C+8] | union{ Ss[65][C+8] , Y1[cop][66] + Y2[64][cop+8] } | per-block parameter stage | ECA scratch.
+// =============================================================================================================
+constexpr int NPF = 8;                     // weight fragments in flight per wave
+
+// LDS element offset of the source row of 3x3 tap t for square sq (or of the zero row for off-board taps)
+__device__ __forceinline__ int im2col_row(int sq, int t, int pitch, int zeroRow) {
+    const int t3 = (t * 11) >> 5;                                       // t / 3 for t in 0..8
+    const int rr = (sq >> 3) + t3 - 1, ff = (sq & 7) + (t - 3 * t3) - 1;
+    return (((unsigned)rr < 8u && (unsigned)ff < 8u) ? rr * 8 + ff : zeroRow) * pitch;
+}
+
+// Fragments travel as four dwords (bit-cast to 8 halfs only at the MFMA): a half-typed vector carried around a loop is
+// re-assembled element by element by the compiler (v_perm storms), and a conditional refill of the prefetch queue makes it
+// drain the queue with vmcnt(0) at every step.  So: no branches around loads (the tail re-requests the last fragment
+// instead — an L1 hit), straight-line bodies.
+typedef int frag4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 h8(frag4 x) { return __builtin_bit_cast(half8, x); }
+__device__ __forceinline__ frag4 lds_frag(const h16* p) { return *reinterpret_cast<const frag4*>(p); }
+
+// One 32x32 output tile, K = ksteps*16: operand X from LDS (`xrow` = this lane's row + 8*(lane>>5) halfs, k-step i at
+// xrow + i*16), operand W = packed fragments from global memory (k-step i of `tile` at wp + i*ws) with NPF requests in
+// flight.  WA = true: the weight fragment is the MFMA's A operand (transposed product D[ch][sq]), else its B operand.
+template <bool WA>
+__device__ __forceinline__ floatx16 gemm_tile(floatx16 acc, const h16* xrow, int ksteps, const h16* w, int ntiles, int tile, int lane) {
+    const frag4* wp = reinterpret_cast<const frag4*>(w) + (size_t)tile * 64 + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const int last = ksteps - 1;
+    frag4 q[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) q[j] = wp[(size_t)(j < last ? j : last) * ws];
+    int base = 0;
+    for (; base + NPF < ksteps; base += NPF) {                         // full groups: refill each slot right after its use
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const frag4 x = lds_frag(xrow + (base + j) * 16);
+            const frag4 f = q[j];
+            const int nxt = base + NPF + j;
+            q[j] = wp[(size_t)(nxt < last ? nxt : last) * ws];
+            acc = WA ? mfma(h8(f), h8(x), acc) : mfma(h8(x), h8(f), acc);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {                                     // last (possibly partial) group: nothing left to request
+        if (base + j < ksteps) {
+            const frag4 x = lds_frag(xrow + (base + j) * 16);
+            acc = WA ? mfma(h8(q[j]), h8(x), acc) : mfma(h8(x), h8(q[j]), acc);
+        }
+    }
+    return acc;
+}
+// 3x3 convolution as an implicit-im2col GEMM: K = 9*cin, k-step (tap, kk) reads X at act + row(tap) + kk*16 + kh.
+// KPT = cin / 16 k-steps per tap = the depth of the weight-fragment queue (the fragments of tap t+1 are requested while
+// tap t multiplies).
+template <int KPT, bool WA>
+__device__ __forceinline__ floatx16 gemm_conv3(floatx16 acc, const h16* act, int sq, int pitch, int zeroRow, int kh, const h16* w, int ntiles, int tile, int lane) {
+    const frag4* wp = reinterpret_cast<const frag4*>(w) + (size_t)tile * 64 + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    frag4 q[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) q[j] = wp[(size_t)j * ws];
+    // taps unrolled (a rolled loop drains the queue at its back edge: the refilled slots are loop-carried copies); the
+    // scheduling barriers keep one tap's loads from being hoisted over the previous taps, which would spill
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const h16* ap = act + im2col_row(sq, t, pitch, zeroRow) + kh;
+#pragma unroll
+        for (int kk = 0; kk < KPT; ++kk) {
+            const frag4 x = lds_frag(ap + kk * 16);
+            const frag4 f = q[kk];
+            if (t < 8) q[kk] = wp[(size_t)((t + 1) * KPT + kk) * ws];
+            acc = WA ? mfma(h8(f), h8(x), acc) : mfma(h8(x), h8(f), acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
+
+// depthwise KxK (+bias, ReLU) for one channel and two board rows; output transposed to y2[sq][ch] with pitch ld2
+template <int K>
+__device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld2, int ch, int g, const h16* wd, float bias) {
+    constexpr int H = K / 2;
+    float wreg[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wreg[i] = (float)wd[i];
+    float in[K + 1][8 + 2 * H];
+#pragma unroll
+    for (int r = 0; r < K + 1; ++r) {
+        const int y = 2 * g - H + r;
+#pragma unroll
+        for (int x = 0; x < 8 + 2 * H; ++x) {
+            const int xx = x - H;
+            in[r][x] = (y >= 0 && y < 8 && xx >= 0 && xx < 8) ? (float)y1[y * 8 + xx] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int ff = 0; ff < 8; ++ff) {
+            float s = bias;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) s += wreg[dy * K + dx] * in[o + dy][ff + dx];
+            }
+            y2[((2 * g + o) * 8 + ff) * ld2 + ch] = (h16)fmaxf(s, 0.0f);
+        }
+    }
+}
+
+template <int CTILES, bool K5>      // CTILES = C / 32 (2 or 4); cin_pad must be 80
+__global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
+                                                              const h16* __restrict__ planes, int n, int copMax, int uHalfs,
+                                                              h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
+                                                              h16* __restrict__ wdl, h16* __restrict__ ml,
+                                                              const int* __restrict__ groupRows, int group,
+                                                              unsigned long long* __restrict__ dbg) {
+    int dbgN = 0;
+#define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const NetDesc& nd = *ndp;
+    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES;       // C = 64 or 128: 2 or 4 column tiles x 2 square tiles
+    h16* Xs = reinterpret_cast<h16*>(smem);                             // [65][ldx]
+    h16* U = Xs + 65 * ldx;                                             // union region
+    h16* Ss = U;                                                        // [65][ldx] (input staging uses pitch ldi)
+    h16* Y1 = U;                                                        // [cop][66]
+    h16* Y2 = U + (size_t)copMax * 66;                                  // [64][cop + 8]
+    float* Pf = reinterpret_cast<float*>(U + uHalfs);                   // per-block parameters: b1[cop], b2[cop], b3[C]  (uHalfs % 8 == 0)
+    h16* Pdw = reinterpret_cast<h16*>(Pf + 2 * copMax + C);             // depthwise weights [cop][k*k]
+    float* Ev = reinterpret_cast<float*>(Pdw + (((size_t)copMax * 25 + 7) & ~(size_t)7));   // ECA / head scratch: [4][C] + [C] + 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = 8 * (lane >> 5);
+    const int stile = wave & 1, ctile = wave >> 1;                      // this wave's tile of an N = C GEMM (ctile < ctiles)
+    const int sqL = stile * 32 + (lane & 31);                           // the square this lane feeds as an A-row / B-column
+    const bool ownsTile = ctile < ctiles;
+
+    for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
+        if (groupRows && (sIdx % group) >= groupRows[sIdx / group]) continue;
+        HM_STAMP();
+        // ---- input planes: NCHW [74][64] fp16 -> Ss as [sq][cin_pad] (+ zero row 64)
+        const int ldi = nd.cin_pad + 8;
+        for (int i = tid; i < 65 * ldi; i += 512) Ss[i] = (h16)0.0f;
+        for (int i = tid; i < ldx; i += 512) Xs[64 * ldx + i] = (h16)0.0f;
+        __syncthreads();
+        const h16* pin = planes + (size_t)sIdx * HM_PLANE_VALUES;
+        for (int i = tid; i < HM_PLANE_VALUES; i += 512) Ss[(i & 63) * ldi + (i >> 6)] = pin[i];
+        __syncthreads();
+        HM_STAMP();   // input staged
+        // ---- stem: 3x3 conv cin -> C (+bias, ReLU)
+        if (ownsTile) {
+            floatx16 acc = gemm_conv3<5, false>(zero16(), Ss, sqL, ldi, 64, kh, wh + nd.stem_w, ctiles, ctile, lane);
+            const int co = ctile * 32 + (lane & 31);
+            const float bias = wf[nd.stem_b + co];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) Xs[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+        }
+        __syncthreads();
+        HM_STAMP();
+        // ---- mobile bottleneck blocks: three phases each over all `cop` expanded channels
+        for (int bi = 0; bi < nd.nblocks; ++bi) {
+            const BlockDesc bd = nd.blk[bi];
+            const int cop = bd.cop, kk = bd.k, ld2 = cop + 8;
+            // parameter stage (consumed from the expand epilogue on): issued first so it overlaps the ECA phase
+            float* sb1 = Pf; float* sb2 = Pf + cop; float* sb3 = Pf + 2 * cop;
+            for (int i = tid; i < cop; i += 512) { sb1[i] = wf[bd.b1 + i]; sb2[i] = wf[bd.b2 + i]; }
+            for (int i = tid; i < C; i += 512) sb3[i] = wf[bd.b3 + i];
+            for (int i = tid; i < cop * kk * kk; i += 512) Pdw[i] = wh[bd.dw + i];
+            if (bd.eca) {   // x = x * hardsigmoid(W_eca . mean_sq(x) + b)   (builder_util.py:49-80, centre tap)
+                float* part = Ev;            // [4][C] partial sums, then partial dot products
+                float* Mv = Ev + 4 * C;      // [C] channel means
+                const int c = tid % C, p = tid / C;                    // 512 / C partitions (4 at C=128, 8 at C=64: use 4)
+                if (p < 4) {
+                    float sacc = 0.0f;
+                    for (int sq = 16 * p; sq < 16 * p + 16; ++sq) sacc += (float)Xs[sq * ldx + c];
+                    part[p * C + c] = sacc;
+                }
+                __syncthreads();
+                if (tid < C) Mv[tid] = (part[tid] + part[C + tid] + part[2 * C + tid] + part[3 * C + tid]) * (1.0f / 64.0f);
+                __syncthreads();
+                if (p < 4) {
+                    const h16* we = wh + bd.ecaw;                       // [ci][co]
+                    const int q4 = C >> 2;
+                    float sacc = 0.0f;
+                    for (int ci0 = p * q4; ci0 < (p + 1) * q4; ci0 += 16) {
+                        h16 wv[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) wv[u] = we[(size_t)(ci0 + u) * C + c];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) sacc += (float)wv[u] * Mv[ci0 + u];
+                    }
+                    part[p * C + c] = sacc;
+                }
+                __syncthreads();
+                if (tid < C) {
+                    const float sg = part[tid] + part[C + tid] + part[2 * C + tid] + part[3 * C + tid] + wf[bd.ecab + tid];
+                    Mv[tid] = fminf(fmaxf(sg * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+                }
+                __syncthreads();
+                for (int i = tid; i < 64 * C; i += 512) {
+                    const int sq = i / C, cc = i - sq * C;
+                    Xs[sq * ldx + cc] = (h16)((float)Xs[sq * ldx + cc] * Mv[cc]);
+                }
+            }
+            __syncthreads();
+            HM_STAMP();   // parameters staged (+ ECA)
+            // phase 1 — 1x1 expand, transposed: Y1[ch][sq] = relu(W1^T x^T + b1); tiles = (cop/32) x 2 over 8 waves
+            {
+                const int copTiles = cop >> 5, tiles = copTiles * 2;
+                const h16* brow = Xs + sqL * ldx + kh;                  // tile's square half = t & 1 == stile when t = wave + 8i
+                for (int t = wave; t < tiles; t += 8) {
+                    const int ct = t >> 1;                              // (t & 1) == (wave & 1) == stile
+                    const floatx16 e = gemm_tile<true>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct, lane);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int ch = ct * 32 + drow(rg, lane);
+                        Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+                    }
+                }
+            }
+            __syncthreads();
+            HM_STAMP();   // expand done
+            // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows)
+            for (int item = tid; item < cop * 4; item += 512) {
+                const int ch = item % cop, g = item / cop;
+                const h16* wd = Pdw + (size_t)ch * kk * kk;
+                if (!K5 || kk == 3) depthwise_rows_ld<3>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
+                else depthwise_rows_ld<5>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
+            }
+            __syncthreads();
+            HM_STAMP();   // depthwise done
+            // phase 3 — 1x1 project + bias + residual: one 32x32 tile per wave, K = cop
+            if (ownsTile) {
+                const floatx16 acc = gemm_tile<false>(zero16(), Y2 + sqL * ld2 + kh, cop >> 4, wh + bd.w2, ctiles, ctile, lane);
+                const int co = ctile * 32 + (lane & 31);
+                const float bias = sb3[co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int sq = stile * 32 + drow(rg, lane);
+                    Xs[sq * ldx + co] = (h16)((float)Xs[sq * ldx + co] + acc[rg] + bias);
+                }
+            }
+            __syncthreads();
+            HM_STAMP();
+        }
+        // ---- value head: 1x1 conv C -> cv (+bias, ReLU), NCHW flatten, linear -> (wdl x3, plys)
+        {
+            const int cv = nd.cv;
+            if (wave < 2) {
+                const floatx16 e = gemm_tile<true>(zero16(), Xs + sqL * ldx + kh, C >> 4, wh + nd.v_w, 1, 0, lane);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int ch = drow(rg, lane);
+                    if (ch < cv) Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + wf[nd.v_b + ch], 0.0f);
+                }
+            }
+            __syncthreads();
+            float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const h16* wl = wh + nd.vl_w;
+            for (int i = tid; i < cv * 64; i += 512) {
+                const float v = (float)Y1[(i >> 6) * 66 + (i & 63)];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] += v * (float)wl[(size_t)o * cv * 64 + i];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float v = part[o];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) Ev[wave * 4 + o] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float lo[4];
+                for (int o = 0; o < 4; ++o) {
+                    float v = wf[nd.vl_b + o];
+                    for (int w8 = 0; w8 < 8; ++w8) v += Ev[w8 * 4 + o];
+                    lo[o] = v;
+                }
+                const float mx = fmaxf(lo[0], fmaxf(lo[1], lo[2]));
+                const float e0 = __expf(lo[0] - mx), e1 = __expf(lo[1] - mx), e2 = __expf(lo[2] - mx);
+                const float inv = 1.0f / (e0 + e1 + e2);
+                value[sIdx] = (h16)((e2 - e0) * inv);
+                wdl[(size_t)sIdx * 3 + 0] = (h16)lo[0]; wdl[(size_t)sIdx * 3 + 1] = (h16)lo[1]; wdl[(size_t)sIdx * 3 + 2] = (h16)lo[2];
+                ml[sIdx] = (h16)(1.0f / (1.0f + __expf(-lo[3])));
+            }
+            __syncthreads();                                             // Y1 (inside U) is about to be overwritten by Ss
+        }
+        HM_STAMP();
+        // ---- policy heads: shared 3x3 conv C -> C (+bias, ReLU) into Ss, then 3x3 C -> 146 (two boards)
+        for (int i = tid; i < ldx; i += 512) Ss[64 * ldx + i] = (h16)0.0f;
+        if (ownsTile) {
+            const floatx16 acc = gemm_conv3<CTILES * 2, false>(zero16(), Xs, sqL, ldx, 64, kh, wh + nd.ps_w, ctiles, ctile, lane);
+            const int co = ctile * 32 + (lane & 31);
+            const float bias = wf[nd.ps_b + co];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) Ss[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+        }
+        __syncthreads();
+        HM_STAMP();
+        {
+            // 146 output planes padded to 160 = 5 channel tiles x 2 square tiles = 10 tiles over 8 waves
+            for (int t = wave; t < 10; t += 8) {
+                const int ct = t >> 1;                                  // (t & 1) == stile
+                const floatx16 e = gemm_conv3<CTILES * 2, true>(zero16(), Ss, sqL, ldx, 64, kh, wh + nd.pp_w, 5, ct, lane);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int ch = ct * 32 + drow(rg, lane);
+                    if (ch < 73) piA[(size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sqL] = (h16)e[rg];
+                    else if (ch < 146) piB[(size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sqL] = (h16)e[rg];
+                }
+            }
+        }
+        __syncthreads();
+        HM_STAMP();
+    }
+#undef HM_STAMP
+}
+
 }  // namespace hmn
 
 // One loaded network: descriptor on the device, launch geometry resolved once.  Re-entrant per handle; no global state.
@@ -452,7 +784,11 @@ struct hm_net {
     void* owned[2] = {nullptr, nullptr};     // parameter buffers this handle allocated (hm_net_create_host), else caller-owned
     size_t lds = 0, stage = 0;
     bool k5 = false;
+    bool narrow = false;                     // C <= 128: the 8-wave latency-first kernel (rise_forward_narrow)
+    int copMax = 0, uHalfs = 0;
+    size_t ldsNarrow = 0;
     int maxBlocks = 1024;
+    int wideRows = 256;                      // batches up to this many rows (one workgroup per CU) run the OCC = 1 instantiation
 };
 
 template <typename K>
@@ -466,14 +802,32 @@ static hipError_t launch_forward(K kern, const hm_net* net, int grid, hipStream_
     return hipGetLastError();
 }
 // applies `f` to the kernel instantiation this network runs on
+template <typename K>
+static hipError_t launch_narrow(K kern, const hm_net* net, int grid, hipStream_t st, const void* d_planes, int n, void* d_value, void* d_pi_a,
+                                void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg) {
+    using namespace hmn;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), net->ldsNarrow, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),
+                       static_cast<const h16*>(d_planes), n, net->copMax, net->uHalfs, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
+                       static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
+                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
+    return hipGetLastError();
+}
 template <typename F>
-static hipError_t with_kernel(const hm_net* net, F f) {
+static hipError_t with_narrow(const hm_net* net, F f) {
+    using namespace hmn;
+    if (net->nd.C == 64) return net->k5 ? f(rise_forward_narrow<2, true>) : f(rise_forward_narrow<2, false>);
+    return net->k5 ? f(rise_forward_narrow<4, true>) : f(rise_forward_narrow<4, false>);
+}
+template <typename F>
+static hipError_t with_kernel(const hm_net* net, bool wide, F f) {
     using namespace hmn;
     switch (net->nd.C / 64) {
-        case 1: return net->k5 ? f(rise_forward_kernel<1, true>) : f(rise_forward_kernel<1, false>);
-        case 2: return net->k5 ? f(rise_forward_kernel<2, true>) : f(rise_forward_kernel<2, false>);
-        case 4: return net->k5 ? f(rise_forward_kernel<4, true>) : f(rise_forward_kernel<4, false>);
-        case 6: return net->k5 ? f(rise_forward_kernel<6, true>) : f(rise_forward_kernel<6, false>);
+        case 1: return wide ? (net->k5 ? f(rise_forward_kernel<1, true, 1>) : f(rise_forward_kernel<1, false, 1>))
+                            : (net->k5 ? f(rise_forward_kernel<1, true, 2>) : f(rise_forward_kernel<1, false, 2>));
+        case 2: return wide ? (net->k5 ? f(rise_forward_kernel<2, true, 1>) : f(rise_forward_kernel<2, false, 1>))
+                            : (net->k5 ? f(rise_forward_kernel<2, true, 2>) : f(rise_forward_kernel<2, false, 2>));
+        case 4: return net->k5 ? f(rise_forward_kernel<4, true, 1>) : f(rise_forward_kernel<4, false, 1>);
+        case 6: return net->k5 ? f(rise_forward_kernel<6, true, 1>) : f(rise_forward_kernel<6, false, 1>);
     }
     return hipErrorInvalidValue;
 }
@@ -507,10 +861,23 @@ int hm_net_create(const int32_t* desc, size_t desc_ints, const void* d_wh, const
     net->lds = lds; net->stage = stage;
     net->d_wh = d_wh; net->d_wf = d_wf;
     if (const char* e = std::getenv("HM_NET_MAX_BLOCKS")) net->maxBlocks = std::atoi(e) > 0 ? std::atoi(e) : 1024;
+    if (const char* e = std::getenv("HM_NET_WIDE_ROWS")) net->wideRows = std::atoi(e);
     if (hipMalloc(&net->d_nd, sizeof(NetDesc)) != hipSuccess) { delete net; return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed"); }
     hipError_t e = hipMemcpy(net->d_nd, &net->nd, sizeof(NetDesc), hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = with_kernel(net, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    for (int wide = 0; wide < 2 && e == hipSuccess; ++wide)
+        e = with_kernel(net, wide != 0, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    if (e == hipSuccess && nd.C <= 128 && nd.cin_pad == 80 && !std::getenv("HM_NET_NO_NARROW")) {
+        int copMax = 32;
+        for (int i = 0; i < nd.nblocks; ++i) copMax = std::max(copMax, nd.blk[i].cop);
+        const size_t ldxN = nd.C + 8, ldi = nd.cin_pad + 8;
+        size_t u = std::max((size_t)copMax * 66 + (size_t)64 * (copMax + 8), (size_t)65 * std::max(ldxN, ldi));
+        u = (u + 7) & ~(size_t)7;
+        const size_t bytes = (65 * ldxN + u) * 2 + (2 * (size_t)copMax + nd.C) * 4 + ((((size_t)copMax * 25 + 7) & ~(size_t)7) * 2) + (5 * (size_t)nd.C + 64) * 4;
+        if (bytes <= 160 * 1024) {
+            net->narrow = true; net->copMax = copMax; net->uHalfs = (int)u; net->ldsNarrow = bytes;
+            e = with_narrow(net, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); });
+        }
+    }
     if (e != hipSuccess) { (void)hipFree(net->d_nd); delete net; return hm_fail(HM_ERR_NO_DEVICE, std::string("hm_net_create: ") + hipGetErrorString(e)); }
     *out = net;
     return 0;
@@ -542,9 +909,14 @@ static int net_forward_impl(const hm_net* net, const void* d_planes, int n, cons
     if (n <= 0) return 0;
     if (d_group_rows && group <= 0) return hm_fail(HM_ERR_INVALID, "group size must be positive");
     const int grid = n < net->maxBlocks ? n : net->maxBlocks;
-    const hipError_t e = with_kernel(net, [&](auto kern) {
-        return launch_forward(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
-    });
+    const bool wide = n <= net->wideRows;           // small batches: one workgroup per CU, full register file
+    const hipError_t e = net->narrow
+        ? with_narrow(net, [&](auto kern) {
+              return launch_narrow(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
+          })
+        : with_kernel(net, wide, [&](auto kern) {
+              return launch_forward(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
+          });
     if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));
     return 0;
 }

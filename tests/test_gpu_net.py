@@ -2,6 +2,9 @@
 form against a plain PyTorch fp32 reference of the same weights.  Tolerance: 1e-3 absolute on value,
 wdl, moves-left, and on policy logits relative to the logit scale (north_star: "value/policy logits
 within 1e-3")."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,12 +39,18 @@ def test_fused_forward_matches_fp32_reference(hm, name):
     torch.cuda.synchronize()
     lib = N.InferenceNet(model)(planes)
     names = ("value", "pi_a", "pi_b", "wdl", "moves_left")
+    report = {}
     for nme, r, g, l in zip(names, ref, got, lib):
         r = r.float().reshape(g.shape)
         scale = max(1.0, float(r.abs().max()))
-        err = float((g.float() - r).abs().max()) / scale
-        err_lib = float((l.float().reshape(g.shape) - r).abs().max()) / scale
-        assert err < 2e-3, (name, nme, err, err_lib, scale)
+        err = float((g.float() - r).abs().max())
+        err_lib = float((l.float().reshape(g.shape) - r).abs().max())
+        # the fp16 output format alone costs half an ulp of the largest logit: 2^-11 * scale
+        report[nme] = dict(max_abs_err=err, library_fp16_err=err_lib, logit_scale=scale, fp16_ulp_at_scale=scale * 2.0 ** -10)
+        assert err / scale < 1e-3, (name, nme, err, err_lib, scale)          # north_star: value / policy logits within 1e-3
+    print("\nnumerics[%s] fused HIP forward vs fp32 torch: %s" % (name, json.dumps(report)))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open(f"gpurun_out/net_numerics_{name}.json", "w"), indent=1)
     # batch-size independence and ragged batches (1 row, odd counts)
     for n in (1, 7, 33):
         sub = fused(planes[:n].contiguous())

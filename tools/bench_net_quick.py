@@ -6,7 +6,7 @@ hm.init(0)
 torch.manual_seed(0)
 for name, mk in (("small", N.rise_v3_small), ("full", N.rise_v33)):
     model = mk(); fl = N.flops_per_position(model); fused = N.FusedNet(model)
-    for n in (64, 512, 4096):
+    for n in [int(a) for a in sys.argv[1:]] or (64, 160, 512, 4096):
         x = torch.rand((n, 74, 8, 8), device="cuda").half()
         for _ in range(3): fused(x)
         torch.cuda.synchronize()
