@@ -77,7 +77,18 @@ struct Node {            // 64 B
     u32 edges, edgeCap, gen;           // arena offsets (8-byte units), 0 = none
     uint16_t depth;
     uint8_t team, flags, type, pad;
-    u32 pad2;
+    u32 posOff;                        // arena offset of this node's NodePos (0 = position not computed yet)
+};
+// Joint position of a node, cached when the node is first reached: a descent walks node ids only and loads the leaf's
+// position instead of replaying the moves of its path (Board::make_moves per level in the reference, searchthread.cc:863-897).
+// Nodes are identified by Board::hash_key, which covers both positions and both per-board key sequences, so a node reached
+// along another path (transposition) has the same record.  repKey = repetition key of each board's position (the key a
+// push on that board appends to its history), hlen / prefix = per-board history length and chained prefix hash at this node.
+struct NodePos {         // 232 B
+    hm_pos pos[2];
+    u64 repKey[2];
+    u64 prefix[2];
+    int hlen[2];
 };
 struct HeapEnt { float prio; uint16_t iA, iB; };
 struct GenHdr {          // candidate generator state in the arena
@@ -93,7 +104,6 @@ struct Ctx {
     uint8_t team, sit, terminal, reserved;
     float termValue;
     u64 leafHash;
-    hm_pos pos[2];
 };
 struct Game {
     // persistent game state (Board + selfplay bookkeeping)
@@ -118,6 +128,7 @@ struct Game {
 struct Params {          // device-visible configuration + pool geometry
     int nGames, nodeCap, ttCap;        // ttCap power of two
     int histGame, histCap;             // per-board history keys: game part / game + search path
+    int ldsNodes;                      // k_collect keeps the game's node pool in LDS (nodeCap * 64 B fits beside its other LDS)
     u32 arenaCap;                      // 8-byte units
     float cpuctInit, cpuctBase, fpuReduction, drawContempt, wdlWeight, mlDiscount;
     int enableTranspositions, enableDynamicFpu, enableWdl;
@@ -227,7 +238,7 @@ __device__ inline int node_alloc(G& s, int team, int depth) {
     if (id >= s.prm->nodeCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 2); return -1; }
     Node n;
     n.hash = 0; n.valueSum = 0.0f; n.visits = 0; n.vvsum = 0; n.expanded = 0; n.endInPly = 0; n.unsolved = 0; n.cntTypes = 0;
-    n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.pad = 0; n.pad2 = 0;
+    n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.pad = 0; n.posOff = 0;
     s.nodes[id] = n;
     return id;
 }
@@ -577,18 +588,76 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
     }
 }
 
-// ---- search path bookkeeping (working board in registers, history keys in the game's pool) ---
+// ---- search path bookkeeping ------------------------------------------------------------------
+// A descent is a walk over node ids; the joint position (two register-resident boards + history view) exists only where it
+// is needed: to give a first-reached child its position and hash, and to classify / encode the leaf.
 struct Path {
     JBoard jb;
     int len;                 // trajectory length
+    int posNode;             // node whose position jb holds (-1: none)
 };
-__device__ inline void path_reset(const G& s, Path& p) {
+__device__ inline void path_reset(const G& s, Path& p) {      // the game's current position (root of every search)
     load_pos(p.jb.bd[0], &s.g->pos[0]);
     load_pos(p.jb.bd[1], &s.g->pos[1]);
     p.jb.hist[0] = s.hist[0]; p.jb.hist[1] = s.hist[1];
     p.jb.hlen[0] = s.g->hlen[0]; p.jb.hlen[1] = s.g->hlen[1];
     p.jb.prefix[0] = s.g->prefix[0]; p.jb.prefix[1] = s.g->prefix[1];
     p.len = 0;
+    p.posNode = -1;
+}
+__device__ __forceinline__ NodePos* nodepos_of(const G& s, const Node& n) { return reinterpret_cast<NodePos*>(s.arena + n.posOff); }
+// jb <- cached position of `node` (which must have one)
+__device__ inline void path_load(const G& s, Path& p, int node) {
+    const NodePos* np = nodepos_of(s, s.nodes[node]);
+    load_pos(p.jb.bd[0], &np->pos[0]);
+    load_pos(p.jb.bd[1], &np->pos[1]);
+    p.jb.hist[0] = s.hist[0]; p.jb.hist[1] = s.hist[1];
+    p.jb.hlen[0] = np->hlen[0]; p.jb.hlen[1] = np->hlen[1];
+    p.jb.prefix[0] = np->prefix[0]; p.jb.prefix[1] = np->prefix[1];
+    p.posNode = node;
+}
+// cache jb as the position of `node`; false when the arena is exhausted (overflow flagged)
+__device__ inline bool path_store(G& s, const RulesTab& rt, const Path& p, int node) {
+    const u32 off = arena_alloc(s, sizeof(NodePos));
+    if (!off) return false;
+    NodePos* np = reinterpret_cast<NodePos*>(s.arena + off);
+    store_pos(&np->pos[0], p.jb.bd[0]);
+    store_pos(&np->pos[1], p.jb.bd[1]);
+    np->repKey[0] = rep_key(rt, p.jb.bd[0]); np->repKey[1] = rep_key(rt, p.jb.bd[1]);
+    np->prefix[0] = p.jb.prefix[0]; np->prefix[1] = p.jb.prefix[1];
+    np->hlen[0] = p.jb.hlen[0]; np->hlen[1] = p.jb.hlen[1];
+    s.nodes[node].posOff = off;
+    return true;
+}
+// History keys of the search path: entry i > 0 of the trajectory appended node i's repetition key to every board that moved
+// on the edge into it (Board::push_move -> record_position, board.h:95-102).  Rebuilt behind the game's keys before the
+// leaf's draw / repetition tests; lane i serves path level i.
+__device__ inline void path_rebuild_history(const G& s, const TrajEnt* traj, int len) {
+    const int lane = threadIdx.x & 63;
+    for (int base = 1; base < len; base += 64) {
+        const int i = base + lane;
+        bool mvA = false, mvB = false;
+        u64 kA = 0, kB = 0;
+        if (i < len) {
+            const TrajEnt t = traj[i];
+            mvA = t.moveA != 0; mvB = t.moveB != 0;
+            const NodePos* np = nodepos_of(s, s.nodes[t.node]);
+            if (mvA) kA = np->repKey[0];
+            if (mvB) kB = np->repKey[1];
+        }
+        // keys of earlier chunks (paths longer than 64 levels) were appended by the previous round
+        const u64 mA = __ballot(mvA), mB = __ballot(mvB);
+        const u64 below = (1ULL << lane) - 1ULL;
+        int offA = 0, offB = 0;
+        for (int b0 = 1; b0 < base; b0 += 64) {   // count moves of the earlier chunks (rare: only for len > 65)
+            const int j = b0 + lane;
+            const bool a = j < base && traj[j].moveA != 0, bb = j < base && traj[j].moveB != 0;
+            offA += __popcll(__ballot(a)); offB += __popcll(__ballot(bb));
+        }
+        if (mvA) s.hist[0][s.g->hlen[0] + offA + __popcll(mA & below)] = kA;
+        if (mvB) s.hist[1][s.g->hlen[1] + offB + __popcll(mB & below)] = kB;
+    }
+    wave_fence();
 }
 
 // searchthread.cc:741-806.  Returns: 0 = not expanded, 1 = expanded, 2 = pending (selection must abort).
@@ -621,12 +690,24 @@ __device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, Traj
     return 0;
 }
 
+// A child reached for the first time gets its position here: parent position (cached) + the edge's joint move.
+// Returns false when the pools are exhausted.
+__device__ __forceinline__ bool position_child(G& s, const RulesTab& rt, Path& p, int parent, int child, u32 ma, u32 mb) {
+    if (p.posNode != parent) path_load(s, p, parent);
+    PROF_T(tm);
+    jb_make(rt, p.jb, ma, mb, false);                      // keys of the path are rebuilt at the leaf (path_rebuild_history)
+    PROF_ADD(4, tm);
+    p.posNode = child;
+    return path_store(s, rt, p, child);
+}
+
 // searchthread.cc:818-916.  Returns leaf node id or -1; traj/p updated.
 __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, bool rootAdv, int rootTeam, bool* reservedOut, u64* unavailMask) {
     int cur = s.g->root;
     bool reserved = false;
     traj[0] = TrajEnt{cur, -1, 0, 0};
     p.len = 1;
+    p.posNode = -1;
     while (true) {
         Node n = s.nodes[cur];
         s.g->nodesVisited++; s.g->edgesScanned += n.expanded;
@@ -641,6 +722,8 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         }
         if (p.len >= MAX_TRAJ - 1) { s.g->overflow |= 4; return -1; }
         int next = -1, childIdx = -1;
+        u32 ma = 0, mb = 0;
+        bool childReserved = false, widened = false;
         PROF_T(tw);
         EdgeScan sc;
         scan_edges(s, n, sc);
@@ -654,54 +737,51 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             const bool got = gen_next(s, *gh, &he);
             PROF_ADD(2, tg);
             if (got) {
-                u32 ma, mb;
                 const float jp = joint_prior(s, *gh, he.iA, he.iB, &ma, &mb);
                 const int child = node_alloc(s, n.team ^ 1, n.depth + 1);
                 Node& nn = s.nodes[cur];
                 Edge* slot = child >= 0 ? edge_append(s, nn) : nullptr;
-                if (slot) {
-                    s.nodes[child].flags |= F_PENDING;
-                    *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 1, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
-                    nn.vvsum++;
-                    childIdx = nn.expanded;
-                    nn.expanded++;
-                    next = child;
-                    bool childReserved = true;
-                    PROF_T(tm);
-                    jb_make(rt, p.jb, ma, mb, true);
-                    PROF_ADD(4, tm);
-                    int pend = -1;
-                    PROF_T(tc);
-                    const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, childReserved, rootAdv, rootTeam, &pend);
-                    PROF_ADD(5, tc);
-                    if (cr == 2) return -1;
-                    traj[p.len - 1].childIdx = childIdx;
-                    traj[p.len] = TrajEnt{next, -1, ma, mb};
-                    p.len++;
-                    if (cr == 1) { cur = next; reserved = false; continue; }
-                    *reservedOut = childReserved;
-                    return next;
-                }
-                return -1;                                    // pool exhausted (overflow flagged)
+                if (!slot) return -1;                         // pool exhausted (overflow flagged)
+                s.nodes[child].flags |= F_PENDING;
+                *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 1, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
+                nn.vvsum++;
+                childIdx = nn.expanded;
+                nn.expanded++;
+                next = child;
+                childReserved = true;
+                widened = true;
             }
         }
-        PROF_T(ts);
-        const Sel sel = select_child_and_apply_virtual_loss(s, cur, n, sc, unavailMask);
-        PROF_ADD(3, ts);
-        if (sel.child < 0 || sel.idx < 0) return -1;
-        next = sel.child; childIdx = sel.idx; reserved = sel.reserved;
-        const Edge ed = edges_of(s, s.nodes[cur])[childIdx];
-        PROF_T(tm);
-        jb_make(rt, p.jb, ed.moveA, ed.moveB, true);
-        PROF_ADD(4, tm);
-        int pend = -1;
-        PROF_T(tc);
-        const int cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, reserved, rootAdv, rootTeam, &pend);
-        PROF_ADD(5, tc);
-        if (cr == 2) return -1;
+        if (!widened) {
+            PROF_T(ts);
+            const Sel sel = select_child_and_apply_virtual_loss(s, cur, n, sc, unavailMask);
+            PROF_ADD(3, ts);
+            if (sel.child < 0 || sel.idx < 0) return -1;
+            next = sel.child; childIdx = sel.idx; childReserved = sel.reserved;
+            const Edge ed = edges_of(s, s.nodes[cur])[childIdx];
+            ma = ed.moveA; mb = ed.moveB;
+        }
+        // Board::make_moves + canonicalize_child, only for a child that has never been reached (no position, hence no hash)
+        int cr;
+        if (s.nodes[next].posOff == 0) {
+            if (!position_child(s, rt, p, cur, next, ma, mb)) return -1;
+            int pend = -1;
+            PROF_T(tc);
+            cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, childReserved, rootAdv, rootTeam, &pend);
+            PROF_ADD(5, tc);
+            if (cr == 2) return -1;
+        } else {
+            cr = (s.nodes[next].flags & F_EXPANDED) ? 1 : 0;  // canonicalize_child's early outs: hash already set
+        }
         traj[p.len - 1].childIdx = childIdx;
-        traj[p.len] = TrajEnt{next, -1, ed.moveA, ed.moveB};
+        traj[p.len] = TrajEnt{next, -1, ma, mb};
         p.len++;
+        if (widened) {
+            if (cr == 1) { cur = next; reserved = false; continue; }
+            *reservedOut = childReserved;
+            return next;
+        }
+        reserved = childReserved;
         cur = next;
     }
     *reservedOut = reserved;
@@ -778,6 +858,7 @@ struct WaveLds {
     u64 board[BATCH][26];    // hm_board images of this batch's network leaves, handed to the plane-writer wave
     int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
     int postBuf;             // which of the two batches (0/1) the posted leaves belong to
+    int listWords;           // wave 1: move-list words written this launch (traffic accounting)
     u32 helperLists[1][HM_MAX_MOVES];   // wave 1: legal list of the leaf board being served
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
@@ -810,8 +891,11 @@ struct NetOut { const uint16_t *value, *piA, *piB, *wdl, *ml; };
 __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int buf, int row, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
     const int lane = threadIdx.x & 63;
     P bd[2];
-    load_pos(bd[0], &ctx.pos[0]);
-    load_pos(bd[1], &ctx.pos[1]);
+    {
+        const NodePos* np = nodepos_of(s, s.nodes[ctx.leaf]);   // cached when the traversal first reached the leaf
+        load_pos(bd[0], &np->pos[0]);
+        load_pos(bd[1], &np->pos[1]);
+    }
     const int team = ctx.team;
     const bool leafAdv = team == rootTeam ? rootAdv : !rootAdv;
     const bool aOn = (int)bd[0].stm == team, bOn = (int)bd[1].stm == (team ^ 1);
@@ -1056,8 +1140,6 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
     while (nctx < BATCH && attempts < BATCH * 2) {
         attempts++;
         PROF_T(t0);
-        path_reset(s, p);
-        PROF_ADD(13, t0);
         bool reserved = false;
         const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
         PROF_ADD(0, t0);
@@ -1092,6 +1174,10 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
         } else {
             int endInPly = 0;
+            PROF_T(tl);
+            if (p.posNode != leaf) path_load(s, p, leaf);          // the leaf's joint position (cached at first reach)
+            path_rebuild_history(s, L.traj, p.len);                // and the repetition keys of its path
+            PROF_ADD(13, tl);
             PROF_T(tk);
             const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
             PROF_ADD(6, tk);
@@ -1111,14 +1197,13 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
                 const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
                 PROF_T(tp);
                 ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
-                store_pos(&ctx.pos[0], p.jb.bd[0]);
-                store_pos(&ctx.pos[1], p.jb.bd[1]);
                 // hm_board image in LDS for the plane writer
                 wave_fence();
                 hm_board* hb = reinterpret_cast<hm_board*>(L.board[valid]);
                 const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
+                store_pos(&hb->pos[0], p.jb.bd[0]);               // every lane writes the same words
+                store_pos(&hb->pos[1], p.jb.bd[1]);
                 if (lane == 0) {
-                    hb->pos[0] = ctx.pos[0]; hb->pos[1] = ctx.pos[1];
                     // last move per board: deepest path move on that board, else the game's last move
                     u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
                     for (int i = 1; i < p.len; ++i) { if (L.traj[i].moveA) lm[0] = L.traj[i].moveA; if (L.traj[i].moveB) lm[1] = L.traj[i].moveB; }
@@ -1266,24 +1351,47 @@ __device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, Wave
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) { pl.leafCounts[base + b] = kept; atomicAdd(&pl.games[g].listWords, kept); }
+        if (lane == 0) { pl.leafCounts[base + b] = kept; L.listWords += kept; }
     }
 }
 
 // Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
 // posts in LDS into fp16 planes, so the 9.4 KB plane writes overlap the next descent instead of extending it.
+//
+// The traversal is a chain of dependent reads (node -> edges -> child nodes -> ...), each an L2 round trip of several
+// hundred cycles for a lone wave.  One block per CU leaves its 160 KB of LDS idle, so the launch first copies the game's
+// whole node pool (64 B per node: 88 KB at nodes = 400) and its Game record into LDS with wide coalesced loads, walks the
+// tree there, and writes both back at the end; edges, generator blocks and the transposition table stay in HBM/L2.
+// Searches whose pool does not fit (prm.ldsNodes == 0) walk the pool in place.
 __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
+    __shared__ __attribute__((aligned(16))) Game s_game;
+    static_assert(sizeof(Game) % 4 == 0 && sizeof(Node) == 64, "LDS mirrors are copied in 4 / 16 byte words");
     PROF_INIT();
     PROF_T(ta);
+    G s = make_view(pl, prm, blockIdx.x);
+    Game* const gGame = s.g;
+    Node* const gNodes = s.nodes;
+    for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += 128) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
-    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; }
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; }
     __syncthreads();
+    const bool searching = s_game.status == ST_SEARCHING;
+    const bool mirror = prm.ldsNodes != 0 && searching;
+    if (mirror) {
+        const int words = s_game.nodeCount * 4;                    // uint4 words
+        const uint4* src = reinterpret_cast<const uint4*>(gNodes);
+        uint4* dst = reinterpret_cast<uint4*>(s_nodes);
+        for (int i = threadIdx.x; i < words; i += 128) dst[i] = src[i];
+        s.nodes = reinterpret_cast<Node*>(s_nodes);
+        __syncthreads();
+    }
+    s.g = &s_game;
     PROF_ADD(9, ta);
     if (threadIdx.x < 64) {
-        G s = make_view(pl, prm, blockIdx.x);
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
         if (threadIdx.x == 0) {
             if (rowsNext) rowsNext[blockIdx.x] = rows;             // batch size of this game for the evaluator
@@ -1304,6 +1412,18 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
             leaf_move_lists(pl, s_rt, L, blockIdx.x, served);
             served++;
         }
+    }
+    __syncthreads();
+    if (searching) {                                               // an idle / finished game was not touched
+        if (threadIdx.x == 0) s_game.listWords += L.listWords;
+        if (mirror) {
+            const int words = s_game.nodeCount * 4;
+            const uint4* src = reinterpret_cast<const uint4*>(s_nodes);
+            uint4* dst = reinterpret_cast<uint4*>(gNodes);
+            for (int i = threadIdx.x; i < words; i += 128) dst[i] = src[i];
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += 128) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
     }
     PROF_FLUSH();
 }
@@ -1459,7 +1579,10 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         }
     }
     const int root = node_alloc(s, team, 0);
+    if (root < 0) { gm.status = ST_ERROR; return; }
     s.nodes[root].hash = rootHash;
+    path_reset(s, p);                                          // the mate scan left p.jb untouched, but be explicit
+    if (!path_store(s, s_rt, p, root)) { gm.status = ST_ERROR; return; }   // the root's position record (every descent starts from it)
     gm.root = root;
     if (prm.enableTranspositions) tt_insert_or_get(s, rootHash, root);
     gm.status = ST_SEARCHING;
@@ -1872,6 +1995,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     p.nodeCap = 3 * (max_nodes + 2 * BATCH) + 64;
     p.histGame = std::max(HIST_GAME_MIN, max_game_plies + 8);        // one key per push on a board, at most one push per macro-ply
     p.histCap = p.histGame + MAX_TRAJ + 8;
+    p.ldsNodes = ((size_t)p.nodeCap * sizeof(Node) <= 118 * 1024 && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
     int tt = 64;
     while (tt < 4 * p.nodeCap) tt <<= 1;
     p.ttCap = tt;
@@ -1880,6 +2004,10 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     p.wdlWeight = c.wdl_value_weight; p.mlDiscount = c.moves_left_discount;
     p.enableTranspositions = c.enable_transpositions; p.enableDynamicFpu = c.enable_dynamic_fpu; p.enableWdl = c.enable_wdl_eval;
     p.qVetoDelta = 0.4f; p.qValueWeight = 1.0f;
+    if (p.ldsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)p.nodeCap * sizeof(Node))) != hipSuccess) {
+        (void)hipGetLastError();
+        p.ldsNodes = 0;                                            // walk the pool in place
+    }
     Pools& pl = sp->pl;
     const size_t G_ = (size_t)n_games;
     int rc = 0;
@@ -1985,7 +2113,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
 
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
-    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(128), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(128), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
                        static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
