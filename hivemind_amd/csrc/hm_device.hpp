@@ -642,6 +642,45 @@ __device__ inline int count_legal(const AttackTab& t, const P& p) {
     return n;
 }
 
+// MoveList<LEGAL>::size() > 0, which is all Board::is_checkmate asks of the lists (board.cc:169-208).  Most positions answer
+// from a few bitboard tests: out of check, a drop (never exposes the own king) or any move of an unpinned non-king piece
+// other than en passant is legal, so the first one found settles it; only positions in check, or with nothing but king /
+// pinned-piece / en-passant moves, take the full count.
+__device__ inline bool has_legal_move(const AttackTab& t, const P& p) {
+    const int us = p.stm, them = us ^ 1;
+    const u64 occ = occ_of(p), ours = bc_of(p, us), theirs = bc_of(p, them);
+    const u64 kbb = p.bt[5] & ours;
+    const int k = lsb(kbb);
+    if (attackers_to(t, p, k, occ, them) == 0) {
+        const u64 empty = ~occ;
+        const u32 hand = us ? p.hand[1] : p.hand[0];
+        if ((hand >> 6) != 0 && empty) return true;                                   // N, B, R or Q in hand
+        if ((hand & 63u) != 0 && (empty & ~(RANK_1 | RANK_8))) return true;           // pawn in hand
+        // pinned pieces (as analyse())
+        u64 snipers = ((rook_att(k, 0) & (p.bt[3] | p.bt[4])) | (bishop_att(t, k, 0) & (p.bt[2] | p.bt[4]))) & theirs;
+        u64 pinned = 0;
+        while (snipers) {
+            const int s = pop_lsb(snipers);
+            const u64 b = between_incl(t, k, s) & ~bit(s) & occ;
+            if (b && !(b & (b - 1)) && (b & ours)) pinned |= b;
+        }
+        const u64 free_ = ours & ~pinned & ~kbb;
+        const u64 fp = p.bt[0] & free_;
+        const u64 up = us == 0 ? fp << 8 : fp >> 8;
+        if (up & empty) return true;                                                  // pawn push (promotions included)
+        const u64 cr = us == 0 ? (fp & ~FILE_H) << 9 : (fp & ~FILE_A) >> 9;
+        const u64 cl = us == 0 ? (fp & ~FILE_A) << 7 : (fp & ~FILE_H) >> 7;
+        if ((cr | cl) & theirs) return true;                                          // pawn capture
+        u64 bb = p.bt[1] & free_;
+        while (bb) if (t.knight[pop_lsb(bb)] & ~ours) return true;
+        bb = (p.bt[2] | p.bt[4]) & free_;
+        while (bb) if (bishop_att(t, pop_lsb(bb), occ) & ~ours) return true;
+        bb = (p.bt[3] | p.bt[4]) & free_;
+        while (bb) if (rook_att(pop_lsb(bb), occ) & ~ours) return true;
+    }
+    return count_legal(t, p) > 0;
+}
+
 // do_move.  Returns pieceToHand as (colour<<3 | pt) or 0 (position.cpp:1459).
 __device__ inline int do_move(const AttackTab& t, const ZobristTab& z, P& p, u32 m) {
     const int us = p.stm, them = us ^ 1;

@@ -158,11 +158,12 @@ __device__ __forceinline__ bool can_partner_provide_blocking_piece(const RulesTa
     return can_partner_blocking_scan((LdsRulesTab)&t, bdA, bdB, boardInCheck, checkedSide, adv, (LdsList)scratch);
 }
 
-// Legal move counts of both boards, computed by lanes 0 and 1 concurrently (wave-uniform call).
+// "Has a legal move" of both boards as 0 / 1 counts (is_checkmate_c only tests its counts against zero), computed by lanes
+// 0 and 1 concurrently (wave-uniform call).
 __device__ inline void legal_counts(const RulesTab& t, const P* bd, int& cntA, int& cntB) {
     const int lane = threadIdx.x & 63;
     int c = 0;
-    if (lane < 2) c = count_legal(t.att, pick_pos(bd, lane));
+    if (lane < 2) c = has_legal_move(t.att, pick_pos(bd, lane)) ? 1 : 0;
     cntA = ulane(c, 0); cntB = ulane(c, 1);
 }
 
@@ -190,11 +191,11 @@ __device__ __attribute__((noinline)) bool is_checkmate_scan(LdsRulesTab tl, cons
     const bool onA = (int)bd[0].stm == side, onB = (int)bd[1].stm == (side ^ 1);
     int cntA = -1, cntB = -1;
     if (onA) {
-        cntA = count_legal(t.att, bd[0]);
+        cntA = has_legal_move(t.att, bd[0]) ? 1 : 0;
         if (cntA == 0 && checkers_of(t.att, bd[0]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 0, side, adv, scratch)) return true;
     }
     if (onB) {
-        cntB = count_legal(t.att, bd[1]);
+        cntB = has_legal_move(t.att, bd[1]) ? 1 : 0;
         if (cntB == 0 && checkers_of(t.att, bd[1]) && !can_partner_provide_blocking_piece(t, bd[0], bd[1], 1, side ^ 1, adv, scratch)) return true;
     }
     if (onA || onB) {

@@ -1372,6 +1372,9 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
     static_assert(sizeof(Game) % 4 == 0 && sizeof(Node) == 64, "LDS mirrors are copied in 4 / 16 byte words");
     PROF_INIT();
     PROF_T(ta);
+#ifdef HM_SEARCH_PROF
+    const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     G s = make_view(pl, prm, blockIdx.x);
     Game* const gGame = s.g;
     Node* const gNodes = s.nodes;
@@ -1398,6 +1401,9 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
             __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_ADD(10, ta);
+#ifdef HM_SEARCH_PROF
+        if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[30] += __builtin_amdgcn_s_memtime() - ta; s_prof[31] += __builtin_amdgcn_s_memrealtime() - rt0_; }
+#endif
     } else {
         uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
         int served = 0;
@@ -1506,7 +1512,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         const int victim = team ^ 1;
         auto no_move_board = [&](const P* nb) {   // necessary condition for is_checkmate(victim, .)
             const bool vA = (int)nb[0].stm == victim, vB = (int)nb[1].stm == (victim ^ 1);
-            return (vA && count_legal(rt.att, nb[0]) == 0) || (vB && count_legal(rt.att, nb[1]) == 0);
+            return (vA && !has_legal_move(rt.att, nb[0])) || (vB && !has_legal_move(rt.att, nb[1]));
         };
         u32* hitCount = reinterpret_cast<u32*>(&L.unavail[0]);
         bool found = false;

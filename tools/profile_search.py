@@ -36,6 +36,8 @@ names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "sel
          "expand: movegen", "expand: softmax", "expand: rank sort", "expand: generator init", "planes: hash+store", "planes: write"]
 it = res.search_iterations
 print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
+if int(buf[31]):
+    print(f"k_collect shader clock: {int(buf[30]) / int(buf[31]) * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
 for i, n in enumerate(names):
     cyc, cnt = int(buf[i]), int(buf[32 + i])
     print(f"{n:28s} cycles/iter {cyc / max(it, 1):10.0f}   calls/iter {cnt / max(it, 1):6.2f}   cycles/call {cyc / max(cnt, 1):9.0f}")
