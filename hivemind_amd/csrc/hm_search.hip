@@ -732,12 +732,14 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         if (widen) {
             // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
             GenHdr* gh = gen_of(s, n);
-            HeapEnt he;
+            GenHdr h = *gh;                                       // header in registers: through the pointer every field access
+            HeapEnt he;                                           // is an L2 round trip that later arena stores force to repeat
             PROF_T(tg);
-            const bool got = gen_next(s, *gh, &he);
+            const bool got = gen_next(s, h, &he);
+            *gh = h;
             PROF_ADD(2, tg);
             if (got) {
-                const float jp = joint_prior(s, *gh, he.iA, he.iB, &ma, &mb);
+                const float jp = joint_prior(s, h, he.iA, he.iB, &ma, &mb);
                 const int child = node_alloc(s, n.team ^ 1, n.depth + 1);
                 Node& nn = s.nodes[cur];
                 Edge* slot = child >= 0 ? edge_append(s, nn) : nullptr;
