@@ -76,7 +76,7 @@ struct Node {            // 64 B
     int visits, vvsum, expanded, endInPly, unsolved, cntTypes;
     u32 edges, edgeCap, gen;           // arena offsets (8-byte units), 0 = none
     uint16_t depth;
-    uint8_t team, flags, type, pad;
+    uint8_t team, flags, type, more;   // more: the candidate generator still holds joint actions (hasNext), kept beside the node
     u32 posOff;                        // arena offset of this node's NodePos (0 = position not computed yet)
 };
 // Joint position of a node, cached when the node is first reached: a descent walks node ids only and loads the leaf's
@@ -217,7 +217,12 @@ struct G {               // per-wave view of one game's pools
     int* leafCounts;         // [2][BATCH][2]
     const Params* prm;
     const Pools* pl;
+    // first tabN entries of the cpuct / progressive-widening tables staged in LDS by the traversal kernel (0: none)
+    const float* ldsCpuct; const uint16_t* ldsPwRoot; const uint16_t* ldsPwNode; int tabN;
 };
+__device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
+__device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : s.pl->pwRoot[v]; }
+__device__ __forceinline__ int pw_node_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwNode[v] : s.pl->pwNode[v]; }
 __device__ __forceinline__ Edge* edges_of(const G& s, const Node& n) { return reinterpret_cast<Edge*>(s.arena + n.edges); }
 __device__ __forceinline__ GenHdr* gen_of(const G& s, const Node& n) { return reinterpret_cast<GenHdr*>(s.arena + n.gen); }
 
@@ -238,7 +243,7 @@ __device__ inline int node_alloc(G& s, int team, int depth) {
     if (id >= s.prm->nodeCap) { if ((threadIdx.x & 63) == 0) atomicOr(&s.g->overflow, 2); return -1; }
     Node n;
     n.hash = 0; n.valueSum = 0.0f; n.visits = 0; n.vvsum = 0; n.expanded = 0; n.endInPly = 0; n.unsolved = 0; n.cntTypes = 0;
-    n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.pad = 0; n.posOff = 0;
+    n.edges = 0; n.edgeCap = 0; n.gen = 0; n.depth = (uint16_t)depth; n.team = (uint8_t)team; n.flags = 0; n.type = T_UNSOLVED; n.more = 0; n.posOff = 0;
     s.nodes[id] = n;
     return id;
 }
@@ -404,14 +409,14 @@ __device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
     }
 }
 __device__ inline bool should_expand_new_child(G& s, const Node& n, const EdgeScan& sc) {
-    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    const bool hasNext = n.more != 0;
     const bool allLose = n.expanded > 0 && !sc.anyNonLosing;
     if (hasNext && allLose) return true;
     if (sc.anyUnvisited) return false;
     int v = n.visits + n.vvsum;
     if (v < 0) v = 0;
     if (v >= MAX_VISITS_TAB) v = MAX_VISITS_TAB - 1;
-    const int allowed = n.depth == 0 ? s.pl->pwRoot[v] : s.pl->pwNode[v];
+    const int allowed = n.depth == 0 ? pw_root_of(s, v) : pw_node_of(s, v);
     return hasNext && n.expanded < allowed;
 }
 
@@ -428,7 +433,7 @@ __device__ inline void update_child_node_type(G& s, Node& n, int idx, uint8_t ct
         n.endInPly = s.nodes[e[idx].child].endInPly + 1;
         return;
     }
-    const bool hasNext = n.gen && gen_of(s, n)->heapSize > 0;
+    const bool hasNext = n.more != 0;
     if (n.unsolved == 0 && (n.flags & F_EXPANDED) && !hasNext) {
         bool allWins = true, hasDrawn = false;
         int longest = 0;
@@ -524,7 +529,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
     const int visits = sc.visits;
     const float sqrtVisits = sqrtf((float)visits);
     int vi = visits < 0 ? 0 : (visits >= MAX_VISITS_TAB ? MAX_VISITS_TAB - 1 : visits);
-    const float c = s.pl->cpuctTab[vi];
+    const float c = cpuct_of(s, vi);
     const float explorationBase = c * sqrtVisits;
     const bool hasNonLosing = sc.anyNonLosing && n.type == T_UNSOLVED;
     const float parentQ = visits > 0 ? (n.valueSum / (float)visits) : 0.0f;
@@ -581,7 +586,8 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
             cn.flags |= F_PENDING;
             reserved = true;
         }
-        e[bestIdx].vloss++;
+        if (bestIdx < 64) e[bestIdx].vloss = ulane(sc.ed.vloss, bestIdx) + 1;      // no read-modify-write round trip
+        else e[bestIdx].vloss++;
         s.nodes[nodeId].vvsum = n.vvsum + 1;
         PROF_ADD(20, tq2);
         return {child, bestIdx, reserved, -1};
@@ -693,12 +699,17 @@ __device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, Traj
 // A child reached for the first time gets its position here: parent position (cached) + the edge's joint move.
 // Returns false when the pools are exhausted.
 __device__ __forceinline__ bool position_child(G& s, const RulesTab& rt, Path& p, int parent, int child, u32 ma, u32 mb) {
+    PROF_T(tl);
     if (p.posNode != parent) path_load(s, p, parent);
+    PROF_ADD(27, tl);
     PROF_T(tm);
     jb_make(rt, p.jb, ma, mb, false);                      // keys of the path are rebuilt at the leaf (path_rebuild_history)
     PROF_ADD(4, tm);
     p.posNode = child;
-    return path_store(s, rt, p, child);
+    PROF_T(tst);
+    const bool ok = path_store(s, rt, p, child);
+    PROF_ADD(28, tst);
+    return ok;
 }
 
 // searchthread.cc:818-916.  Returns leaf node id or -1; traj/p updated.
@@ -727,6 +738,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         PROF_T(tw);
         EdgeScan sc;
         scan_edges(s, n, sc);
+        PROF_ADD(29, tw);
         const bool widen = should_expand_new_child(s, n, sc);
         PROF_ADD(1, tw);
         if (widen) {
@@ -737,6 +749,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             PROF_T(tg);
             const bool got = gen_next(s, h, &he);
             *gh = h;
+            s.nodes[cur].more = h.heapSize > 0;
             PROF_ADD(2, tg);
             if (got) {
                 const float jp = joint_prior(s, h, he.iA, he.iB, &ma, &mb);
@@ -760,8 +773,8 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             PROF_ADD(3, ts);
             if (sel.child < 0 || sel.idx < 0) return -1;
             next = sel.child; childIdx = sel.idx; childReserved = sel.reserved;
-            const Edge ed = edges_of(s, s.nodes[cur])[childIdx];
-            ma = ed.moveA; mb = ed.moveB;
+            if (childIdx < 64) { ma = (u32)ulane((int)sc.ed.moveA, childIdx); mb = (u32)ulane((int)sc.ed.moveB, childIdx); }   // edge held by lane childIdx
+            else { const Edge ed = edges_of(s, s.nodes[cur])[childIdx]; ma = ed.moveA; mb = ed.moveB; }
         }
         // Board::make_moves + canonicalize_child, only for a child that has never been reached (no position, hence no hash)
         int cr;
@@ -884,6 +897,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.leafMoves = pl.leafMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES;
     s.leafCounts = pl.leafCounts + (size_t)g * 2 * BATCH * 2;
     s.prm = &prm; s.pl = &pl;
+    s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
     return s;
 }
 
@@ -1033,6 +1047,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     // only the fields expansion owns: the backups of this batch update visits / value sum of the same node concurrently
     Node* np = &s.nodes[ctx.leaf];
     np->gen = leaf.gen; np->edges = leaf.edges; np->edgeCap = leaf.edgeCap; np->expanded = leaf.expanded;
+    np->more = h.heapSize > 0;
     wave_fence();
     if ((leaf.flags & F_EXPANDED) && lane == 0) node_set_flag(np, F_EXPANDED);
     PROF_ADD(24, te4);
@@ -1371,6 +1386,9 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     __shared__ __attribute__((aligned(16))) Game s_game;
+    constexpr int TABN = 512;                                      // visits beyond this read the tables in HBM
+    __shared__ float s_cpuct[TABN];
+    __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
     static_assert(sizeof(Game) % 4 == 0 && sizeof(Node) == 64, "LDS mirrors are copied in 4 / 16 byte words");
     PROF_INIT();
     PROF_T(ta);
@@ -1382,6 +1400,7 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
     Node* const gNodes = s.nodes;
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += 128) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
+    for (int i = threadIdx.x; i < TABN; i += 128) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
     if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
@@ -1395,6 +1414,7 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
         __syncthreads();
     }
     s.g = &s_game;
+    s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
     PROF_ADD(9, ta);
     if (threadIdx.x < 64) {
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);

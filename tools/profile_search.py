@@ -33,7 +33,7 @@ fn(buf.ctypes.data, 0)
 names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "select_child(puct)", "jb_make", "canonicalize_child",
          "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total", "path_reset", "process: backup_batch",
          "classify: legal_counts", "classify: checkmate x2", "classify: draw", "classify: waiting-board mate", "puct: pass 1", "puct: arg-max loop",
-         "expand: movegen", "expand: softmax", "expand: rank sort", "expand: generator init", "planes: hash+store", "planes: write"]
+         "expand: movegen", "expand: softmax", "expand: rank sort", "expand: generator init", "planes: hash+store", "planes: write", "position_child: path_load", "position_child: path_store", "scan_edges"]
 it = res.search_iterations
 print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
 if int(buf[31]):
