@@ -159,6 +159,11 @@ struct Pools {
 // small device helpers
 // ---------------------------------------------------------------------------------------
 __device__ unsigned long long g_prof[64];      // hm_prof.hpp probes (all zero in the product build)
+#ifdef HM_SEARCH_PROF
+constexpr int PROF_LAUNCHES = 8192;
+__device__ unsigned int g_colDur[PROF_LAUNCHES][64];   // traversal cycles of wave 0 per (k_collect launch, game slot < 64): straggler analysis
+__device__ unsigned int g_colLaunch;                    // launch counter, bumped by k_process
+#endif
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1425,6 +1430,7 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
         PROF_ADD(10, ta);
 #ifdef HM_SEARCH_PROF
         if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[30] += __builtin_amdgcn_s_memtime() - ta; s_prof[31] += __builtin_amdgcn_s_memrealtime() - rt0_; }
+        if (threadIdx.x == 0 && blockIdx.x < 64 && searching && g_colLaunch < PROF_LAUNCHES) g_colDur[g_colLaunch][blockIdx.x] = (unsigned int)(__builtin_amdgcn_s_memtime() - ta);
 #endif
     } else {
         uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
@@ -1464,6 +1470,9 @@ __global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params p
     __syncthreads();
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
+#ifdef HM_SEARCH_PROF
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_colLaunch++;
+#endif
     PROF_FLUSH();
 }
 
@@ -2202,6 +2211,16 @@ int hm_sp_profile(unsigned long long* out64, int reset) {
     if (out64) HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));
     if (reset) { unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
     return HM_OK;
+}
+int hm_sp_profile_launches(unsigned int* out, int launches) {   // [launches][64] traversal cycles per k_collect launch and game slot
+#ifdef HM_SEARCH_PROF
+    if (!out || launches < 0 || launches > PROF_LAUNCHES) return hm_fail(HM_ERR_INVALID, "bad launch count");
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_colDur), sizeof(unsigned int) * 64 * (size_t)launches));
+    return HM_OK;
+#else
+    (void)out; (void)launches;
+    return hm_fail(HM_ERR_STATE, "library built without -DHM_SEARCH_PROF");
+#endif
 }
 int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream) {
     HIPCHK(hipMemcpyAsync(pinned_out, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, stream));

@@ -47,6 +47,7 @@ _SIGS = {
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
     "hm_sp_classify": (_i, [_vp, _vp, _vp]),
     "hm_sp_profile": (_i, [_vp, _i]),
+    "hm_sp_profile_launches": (_i, [_vp, _i]),
     "hm_sp_trace_select": (_i, [_i]),
     "hm_sp_trace": (_i, [_vp, _i]),
 }

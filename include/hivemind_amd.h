@@ -238,6 +238,7 @@ int hm_sp_classify(hm_sp* sp, const int* args4, int* out4);
  * event log of collect_batch for one game slot, encoded as oracle Search::ctxTrace (library built with
  * -DHM_SEARCH_TRACE; tools/dbg_ctx.py).  hm_sp_trace returns the number of events logged. */
 int hm_sp_profile(unsigned long long* out64, int reset);
+int hm_sp_profile_launches(unsigned int* out, int launches);   /* [launches][64] wave-0 cycles per k_collect launch and game slot */
 int hm_sp_trace_select(int game);
 int hm_sp_trace(unsigned long long* out, int cap);
 

@@ -14,7 +14,7 @@
 //     repetition history, hash_key.
 //   * perft (tools/benchmark.cc:59-76).
 // Pinning: validated move-for-move against the reference's own sources built
-// into oracle/_ref/libhmref.so (oracle/difftest.cc, tests/test_oracle_vs_ref.py)
+// into oracle/_ref/libhmref.so (oracle/difftest.cc, tests/test_oracle_golden.py)
 // and against the reference's gtest known answers (tests/golden/*.json).
 #pragma once
 #include <algorithm>

@@ -2,11 +2,17 @@
 //
 // TEST INFRASTRUCTURE ONLY (see bughouse.hpp).  PARITY STATUS: the reference's search/*.cc and
 // tools/selfplay.cc cannot be built in this image (they include nn/engine.h -> TensorRT and
-// <cuda_fp16.h> -> <nv/target>, both absent), so this restatement is pinned only by the
-// reference's own known answers that do not need those files (PW schedule, cpuct, sit rules:
-// tests/golden/pw_schedule.json, tests/test_oracle_search.py) — "parity unpinned" for the
-// select/expand/backup loop itself.  Every function cites the reference lines it follows
-// (paths relative to engine/src).
+// <cuda_fp16.h> -> <nv/target>, both absent), so this restatement is pinned by the reference's own
+// known answers instead: 47 gtest cases of engine/tests/test_move_gen.cc (backup perspective, solver
+// propagation, classify_terminal_position incl. the waiting-board mate, collision cancel, softmax
+// robustness, moves-left discount, progressive-widening gates, virtual-loss / pending-evaluation
+// diversion, dynamic FPU, transposition edges, best-move rule, Q/solver at depth) transcribed as
+// data in tests/golden/search_cases.json and replayed through oracle/oracle_lab.cc
+// (tests/test_oracle_search_cases.py; every reference TEST is either a case or listed with the
+// reason it is out of scope), plus the PW schedule / cpuct / sit rules from the reference build
+// (tests/golden/pw_schedule.json, tests/test_oracle_search.py).  What stays unpinned: a whole
+// multi-hundred-node search has no reference-held expected visit vector in the tree.
+// Every function cites the reference lines it follows (paths relative to engine/src).
 //
 // Schedule restated: Agent(1) — one SearchThread, batch size B=8, double-buffered lookahead
 // (searchthread.cc:661-708), node budget loop (agent.cc:331-341), finish_pending_iteration.

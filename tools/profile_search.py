@@ -25,7 +25,7 @@ torch.manual_seed(0)
 fn = _lib.lib.hm_sp_profile
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
 buf = np.zeros(64, dtype=np.uint64)
-cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=1, concurrent_games=games, max_macro_plies=40)
+cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=1, concurrent_games=games, max_macro_plies=int(os.environ.get("PLIES", 40)))
 sp = hm.SelfPlay(cfg, N.FusedNet(N.rise_v3_small()))
 fn(None, 1)
 res = sp.run()
@@ -41,3 +41,18 @@ if int(buf[31]):
 for i, n in enumerate(names):
     cyc, cnt = int(buf[i]), int(buf[32 + i])
     print(f"{n:28s} cycles/iter {cyc / max(it, 1):10.0f}   calls/iter {cnt / max(it, 1):6.2f}   cycles/call {cyc / max(cnt, 1):9.0f}")
+
+# straggler analysis: wave-0 traversal cycles per (k_collect launch, game slot); a launch lasts as long as its slowest game
+L = 8192
+dur = np.zeros((L, 64), dtype=np.uint32)
+if _lib.lib.hm_sp_profile_launches(dur.ctypes.data, L) == 0:
+    live = dur > 0
+    rows = live.any(axis=1)
+    d = dur[rows].astype(np.float64); lv = live[rows]
+    mx = d.max(axis=1); mean = d.sum(axis=1) / lv.sum(axis=1)
+    print(f"launches {rows.sum()}  live games/launch {lv.sum(axis=1).mean():.1f}  mean-of-max {mx.mean():.0f}  mean-of-mean {mean.mean():.0f}  ratio {mx.mean() / mean.mean():.2f}")
+    for q in (16, 8, 4):
+        # the same games split into groups of q slots, each group waiting only for its own slowest game
+        gm = [np.where(lv[:, i:i + q].any(axis=1), d[:, i:i + q].max(axis=1), np.nan) for i in range(0, 64, q)]
+        print(f"  groups of {q:2d}: mean group max {np.nanmean(np.stack(gm)):.0f}")
+    print(f"leg ms/iter: collect {res.collect_ms / it:.4f} net {res.eval_ms / it:.4f} process {res.process_ms / it:.4f}; wall per iter {res.seconds / it * 1e3:.4f}")
