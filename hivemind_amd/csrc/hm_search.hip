@@ -56,6 +56,7 @@ constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown t
 constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
 constexpr int MAX_VISITS_TAB = 1 << 15;  // cpuct / PW tables
 constexpr int NLISTS = 8;                // LDS scratch move lists per wave
+constexpr int COLLECT_THREADS = 192;     // k_collect: traversal wave, classifier wave, plane-writer wave
 constexpr float Q_INIT = -1.0f;
 
 enum : uint8_t { T_UNSOLVED = 0, T_WIN = 1, T_LOSS = 2, T_DRAW = 3 };
@@ -224,7 +225,17 @@ struct G {               // per-wave view of one game's pools
     const Pools* pl;
     // first tabN entries of the cpuct / progressive-widening tables staged in LDS by the traversal kernel (0: none)
     const float* ldsCpuct; const uint16_t* ldsPwRoot; const uint16_t* ldsPwNode; int tabN;
+    // k_collect's traversal wave hands every unsolved leaf to the block's classifier wave and goes on selecting; `inflight`
+    // is the leaf whose classification has not been acknowledged yet (-1: none).  Its Node must not be read before svc_wait.
+    int inflight, reqSeq;
+    const int* ackSeq;
 };
+// blocks until the classifier wave has finished the outstanding leaf (its writes to the leaf's Node / context are visible after)
+__device__ __forceinline__ void svc_wait(G& s) {
+    if (s.inflight < 0) return;
+    while (__hip_atomic_load(s.ackSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.reqSeq) __builtin_amdgcn_s_sleep(1);
+    s.inflight = -1;
+}
 __device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
 __device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : s.pl->pwRoot[v]; }
 __device__ __forceinline__ int pw_node_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwNode[v] : s.pl->pwNode[v]; }
@@ -398,8 +409,11 @@ __device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
         const int i = base + lane;
         float pr = 0.0f;
         bool counted = false, nonLosing = false, unvisited = false;
+        Edge ed;
+        ed.child = -2;
+        if (i < limit) ed = e[i];
+        if (s.inflight >= 0 && wave_any(ed.child == s.inflight)) svc_wait(s);   // a child whose terminal test is still running
         if (i < limit) {
-            const Edge ed = e[i];
             const int ct = s.nodes[ed.child].type;
             if (base == 0) { o.ed = ed; o.ct = ct; }
             pr = ed.prior;
@@ -680,6 +694,7 @@ __device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, Traj
     const u64 h = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), childAdv, rt.zob.time_adv);
     c0.hash = h;
     const int canonical = tt_insert_or_get(s, h, child);
+    if (canonical == s.inflight) svc_wait(s);
     bool isAncestor = false;
     for (int i = 0; i < p.len; ++i) isAncestor |= traj[i].node == canonical;
     const bool teamMismatch = s.nodes[canonical].team != c0.team;
@@ -725,6 +740,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
     p.len = 1;
     p.posNode = -1;
     while (true) {
+        if (cur == s.inflight) svc_wait(s);
         Node n = s.nodes[cur];
         s.g->nodesVisited++; s.g->edgesScanned += n.expanded;
         if (n.type != T_UNSOLVED) break;
@@ -884,6 +900,13 @@ struct WaveLds {
     uint32_t pval[HM_NB_PLANES + 6];
     u64 unavail[8];
     TrajEnt traj[MAX_TRAJ];
+    // traversal wave -> classifier wave (k_collect): one leaf in flight
+    TrajEnt trajReq[MAX_TRAJ];       // the leaf's path (copied: the traversal reuses `traj` for its next descent)
+    int reqLeaf, reqTrajLen, reqCtxIdx, reqBuf, reqReserved, reqFirst;
+    int reqSeq, ackSeq, svcStop;     // reqSeq: requests posted; ackSeq: requests finished; svcStop: no more requests in this launch
+    int reqResult;                   // outcome of the last finished request: 0 network leaf, 1 terminal, 2 dropped (not reserved)
+    int svcValid;                    // network leaves of the current batch so far (= plane rows posted)
+    int batchLeaf[BATCH];            // leaves of the batch being collected (same-batch collision test)
 };
 
 __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
@@ -903,6 +926,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.leafCounts = pl.leafCounts + (size_t)g * 2 * BATCH * 2;
     s.prm = &prm; s.pl = &pl;
     s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
+    s.inflight = -1; s.reqSeq = 0; s.ackSeq = nullptr;
     return s;
 }
 
@@ -1153,10 +1177,74 @@ __device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
     s.g->validCount[buf] = 0;
 }
 
-// collect_batch (searchthread.cc:255-442).  Planes of NN leaves go to planesOut + slot*4736 (fp16).
-__device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, uint16_t* planesOut) {
+// collect_batch (searchthread.cc:255-442), split over two waves of the game's block.  The traversal wave (below) selects
+// leaves; every unsolved leaf is handed to the classifier wave (serve_leaf), which runs the terminal test
+// (classify_terminal_position :99-139), completes the context record and, for a network leaf, posts the hm_board image to the
+// plane-writer wave — while the traversal is already descending again.  The hand-off keeps the sequential semantics: the
+// traversal never reads the Node of a leaf whose request is outstanding (svc_wait guards in scan_edges / select_and_expand /
+// canonicalize_child), one request is in flight at a time, and requests are served in order, so context slots and plane rows
+// are assigned exactly as the single-threaded loop assigns them.
+__device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv) {
     const int lane = threadIdx.x & 63;
-    int nctx = 0, valid = 0, attempts = 0;
+    const int leaf = L.reqLeaf, len = L.reqTrajLen, buf = L.reqBuf, slot = L.reqCtxIdx;
+    const bool reserved = L.reqReserved != 0;
+    const int valid = L.reqFirst ? 0 : L.svcValid;
+    Ctx ctx;
+    ctx.leaf = leaf; ctx.trajLen = len; ctx.reserved = reserved;
+    ctx.team = s.nodes[leaf].team;
+    ctx.sit = ((ctx.team == rootTeam) == rootAdv) ? 1 : 0;
+    ctx.terminal = 0; ctx.termValue = 0.0f; ctx.leafHash = 0;
+    const int searchPly = len - 1;
+    const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
+    Path p;
+    path_load(s, p, leaf);                                     // the leaf's joint position (cached at first reach)
+    path_rebuild_history(s, L.trajReq, len);                   // and the repetition keys of its path
+    int endInPly = 0, result = 0, newValid = valid;
+    const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
+    if (to != 0) {
+        ctx.terminal = 1;
+        result = 1;
+        Node& ln = s.nodes[leaf];
+        if (to == 1) { ctx.termValue = 1.0f; ln.type = T_WIN; ln.valueSum = 1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
+        else if (to == 2) { ctx.termValue = -1.0f; ln.type = T_LOSS; ln.valueSum = -1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
+        else { ctx.termValue = drawValue; ln.type = T_DRAW; ln.endInPly = 1; }
+    } else if (!reserved) {
+        result = 2;                                            // the traversal cancels the path's virtual losses
+    } else {
+        const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
+        ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
+        // hm_board image in LDS for the plane writer
+        wave_fence();
+        hm_board* hb = reinterpret_cast<hm_board*>(L.board[valid]);
+        const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
+        store_pos(&hb->pos[0], p.jb.bd[0]);                   // every lane writes the same words
+        store_pos(&hb->pos[1], p.jb.bd[1]);
+        if (lane == 0) {
+            // last move per board: deepest path move on that board, else the game's last move
+            u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
+            for (int i = 1; i < len; ++i) { if (L.trajReq[i].moveA) lm[0] = L.trajReq[i].moveA; if (L.trajReq[i].moveB) lm[1] = L.trajReq[i].moveB; }
+            hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
+            hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
+            hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
+        }
+        wave_fence();
+        // the planes are written by the third wave of the block
+        if (lane == 0) { L.postBuf = buf; __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        newValid = valid + 1;
+    }
+    if (result != 2) {
+        s.ctx[buf * BATCH + slot] = ctx;
+        TrajEnt* dst = s.traj + (size_t)(buf * BATCH + slot) * MAX_TRAJ;
+        for (int i = lane; i < len; i += 64) dst[i] = L.trajReq[i];
+    }
+    if (lane == 0) { L.reqResult = result; L.svcValid = newValid; }
+    wave_fence();
+}
+
+__device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv) {
+    const int lane = threadIdx.x & 63;
+    int nctx = 0, attempts = 0;
+    bool posted = false;
     Path p;
     TRACE_SEQ();
     while (nctx < BATCH && attempts < BATCH * 2) {
@@ -1172,89 +1260,65 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             continue;
         }
         bool collision = false;
-        for (int i = 0; i < nctx; ++i) collision |= s.ctx[buf * BATCH + i].leaf == leaf;
+        for (int i = 0; i < nctx; ++i) collision |= L.batchLeaf[i] == leaf;
         if (collision) {
             TRACE_EV(2, p.len, 0);
             s.g->sameBatchCollisions++;
+            if (leaf == s.inflight) svc_wait(s);
             if (reserved) s.nodes[leaf].flags &= ~F_PENDING;
             cancel_virtual_losses(s, L.traj, p.len);
             continue;
         }
-        Ctx ctx;
-        ctx.leaf = leaf; ctx.trajLen = p.len; ctx.reserved = reserved;
-        ctx.team = s.nodes[leaf].team;
-        ctx.sit = ((ctx.team == rootTeam) == rootAdv) ? 1 : 0;
-        ctx.terminal = 0; ctx.termValue = 0.0f; ctx.leafHash = 0;
         const int searchPly = p.len - 1;
         if (searchPly > s.g->maxDepth) s.g->maxDepth = searchPly;
-        const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
+        if (leaf == s.inflight) svc_wait(s);
         const uint8_t solved = s.nodes[leaf].type;
         bool keep = true;
         if (solved != T_UNSOLVED) {
             TRACE_EV(3, p.len, solved);
-            ctx.terminal = 1;
+            Ctx ctx;
+            ctx.leaf = leaf; ctx.trajLen = p.len; ctx.reserved = reserved;
+            ctx.team = s.nodes[leaf].team;
+            ctx.sit = ((ctx.team == rootTeam) == rootAdv) ? 1 : 0;
+            ctx.terminal = 1; ctx.leafHash = 0;
+            const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
             ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
-        } else {
-            int endInPly = 0;
-            PROF_T(tl);
-            if (p.posNode != leaf) path_load(s, p, leaf);          // the leaf's joint position (cached at first reach)
-            path_rebuild_history(s, L.traj, p.len);                // and the repetition keys of its path
-            PROF_ADD(13, tl);
-            PROF_T(tk);
-            const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
-            PROF_ADD(6, tk);
-            if (to != 0) {
-                TRACE_EV(4, p.len, to | (endInPly << 4));
-                ctx.terminal = 1;
-                Node& ln = s.nodes[leaf];
-                if (to == 1) { ctx.termValue = 1.0f; ln.type = T_WIN; ln.valueSum = 1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
-                else if (to == 2) { ctx.termValue = -1.0f; ln.type = T_LOSS; ln.valueSum = -1.0f * (float)(ln.visits + 1); ln.endInPly = endInPly; }
-                else { ctx.termValue = drawValue; ln.type = T_DRAW; ln.endInPly = 1; }
-            } else if (!ctx.reserved) {
-                TRACE_EV(5, p.len, 0);
-                s.g->reservationCollisions++;
-                cancel_virtual_losses(s, L.traj, p.len);
-                keep = false;
-            } else {
-                const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
-                PROF_T(tp);
-                ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
-                // hm_board image in LDS for the plane writer
-                wave_fence();
-                hm_board* hb = reinterpret_cast<hm_board*>(L.board[valid]);
-                const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
-                store_pos(&hb->pos[0], p.jb.bd[0]);               // every lane writes the same words
-                store_pos(&hb->pos[1], p.jb.bd[1]);
-                if (lane == 0) {
-                    // last move per board: deepest path move on that board, else the game's last move
-                    u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
-                    for (int i = 1; i < p.len; ++i) { if (L.traj[i].moveA) lm[0] = L.traj[i].moveA; if (L.traj[i].moveB) lm[1] = L.traj[i].moveB; }
-                    hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
-                    hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
-                    hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
-                }
-                wave_fence();
-                PROF_ADD(25, tp);
-                PROF_T(tw);
-                // the planes are written by the second wave of the block while this one goes on selecting
-                if (lane == 0) { L.postBuf = buf; __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-                (void)planesOut;
-                PROF_ADD(26, tw);
-                PROF_ADD(7, tp);
-                TRACE_EV(6, p.len, 0);
-                valid++;
-            }
-        }
-        if (keep) {
-            PROF_T(tx);
             s.ctx[buf * BATCH + nctx] = ctx;
             TrajEnt* dst = s.traj + (size_t)(buf * BATCH + nctx) * MAX_TRAJ;
             for (int i = lane; i < p.len; i += 64) dst[i] = L.traj[i];
             wave_fence();
+        } else {
+            PROF_T(tk);
+            svc_wait(s);                                           // one request in flight
+            for (int i = lane; i < p.len; i += 64) L.trajReq[i] = L.traj[i];
+            if (lane == 0) {
+                L.reqLeaf = leaf; L.reqTrajLen = p.len; L.reqCtxIdx = nctx; L.reqBuf = buf; L.reqReserved = reserved ? 1 : 0;
+                L.reqFirst = posted ? 0 : 1;
+            }
+            wave_fence();
+            s.reqSeq++;
+            if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            s.inflight = leaf;
+            posted = true;
+            if (!reserved) {                                       // rare: whether the context is kept depends on the terminal test
+                svc_wait(s);
+                if (L.reqResult == 2) {
+                    TRACE_EV(5, p.len, 0);
+                    s.g->reservationCollisions++;
+                    cancel_virtual_losses(s, L.traj, p.len);
+                    keep = false;
+                }
+            }
+            PROF_ADD(6, tk);
+        }
+        if (keep) {
+            if (lane == 0) L.batchLeaf[nctx] = leaf;
+            wave_fence();
             nctx++;
-            PROF_ADD(8, tx);
         }
     }
+    svc_wait(s);
+    const int valid = posted ? L.svcValid : 0;
     s.g->ctxCount[buf] = nctx;
     s.g->validCount[buf] = valid;
     s.g->evalRows += valid;
@@ -1273,14 +1337,14 @@ __device__ __forceinline__ int collect_step(G& s, const RulesTab& rt, WaveLds& L
     if (s.g->status != ST_SEARCHING) return 0;
     const int rootTeam = s.g->team;
     const bool rootAdv = s.g->adv != 0;
-    uint16_t* nxt = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
+    (void)planesNext; (void)g;
     // worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678).  One collect_batch call
     // site: with nothing in flight the first batch goes to buffer 0, otherwise the lookahead to the other one.
     for (;;) {
         if (s.g->nodesSearched >= s.g->targetNodes || s.nodes[s.g->root].type != T_UNSOLVED || s.g->overflow) { s.g->status = ST_FINISHING; return 0; }
         const bool first = s.g->pending < 0;
         const int buf = first ? 0 : 1 - s.g->pending;
-        collect_batch(s, rt, L, buf, rootTeam, rootAdv, nxt);
+        collect_batch(s, rt, L, buf, rootTeam, rootAdv);
         if (!first) return s.g->validCount[buf];
         if (s.g->ctxCount[0] == 0) { s.g->overflow |= 16; s.g->status = ST_FINISHING; return 0; }   // no progress possible
         if (s.g->validCount[0] == 0) { process_batch(s, rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0); continue; }
@@ -1385,7 +1449,7 @@ __device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, Wave
 // whole node pool (64 B per node: 88 KB at nodes = 400) and its Game record into LDS with wide coalesced loads, walks the
 // tree there, and writes both back at the end; edges, generator blocks and the transposition table stay in HBM/L2.
 // Searches whose pool does not fit (prm.ldsNodes == 0) walk the pool in place.
-__global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
+__global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
     __shared__ RulesTab s_rt;
@@ -1403,10 +1467,10 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
     G s = make_view(pl, prm, blockIdx.x);
     Game* const gGame = s.g;
     Node* const gNodes = s.nodes;
-    for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += 128) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
+    for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
-    for (int i = threadIdx.x; i < TABN; i += 128) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
-    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; }
+    for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.reqSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
     const bool mirror = prm.ldsNodes != 0 && searching;
@@ -1414,28 +1478,47 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
         const int words = s_game.nodeCount * 4;                    // uint4 words
         const uint4* src = reinterpret_cast<const uint4*>(gNodes);
         uint4* dst = reinterpret_cast<uint4*>(s_nodes);
-        for (int i = threadIdx.x; i < words; i += 128) dst[i] = src[i];
+        for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
         s.nodes = reinterpret_cast<Node*>(s_nodes);
         __syncthreads();
     }
     s.g = &s_game;
     s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
     PROF_ADD(9, ta);
-    if (threadIdx.x < 64) {
+    const int wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        s.ackSeq = &L.ackSeq;
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
         if (threadIdx.x == 0) {
             if (rowsNext) rowsNext[blockIdx.x] = rows;             // batch size of this game for the evaluator
-            __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_ADD(10, ta);
 #ifdef HM_SEARCH_PROF
         if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[30] += __builtin_amdgcn_s_memtime() - ta; s_prof[31] += __builtin_amdgcn_s_memrealtime() - rt0_; }
         if (threadIdx.x == 0 && blockIdx.x < 64 && searching && g_colLaunch < PROF_LAUNCHES) g_colDur[g_colLaunch][blockIdx.x] = (unsigned int)(__builtin_amdgcn_s_memtime() - ta);
 #endif
+    } else if (wave == 1) {
+        // classifier: serves the traversal's leaf requests in order; ends once the traversal has stopped and every request is served
+        const int rootTeam = s_game.team;
+        const bool rootAdv = s_game.adv != 0;
+        int seen = 0;
+        for (;;) {
+            int rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rs == seen) {
+                if (!__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(1); continue; }
+                rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rs == seen) break;
+            }
+            serve_leaf(s, s_rt, L, rootTeam, rootAdv);
+            seen = rs;
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
         int served = 0;
-        for (;;) {                                                 // ends once wave 0 has set `done` and every post is served
+        for (;;) {                                                 // ends once the classifier has set `done` and every post is served
             int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (served >= posted) {
                 if (!__hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(4); continue; }
@@ -1454,10 +1537,10 @@ __global__ __launch_bounds__(128) void k_collect(Pools pl, Params prm, uint16_t*
             const int words = s_game.nodeCount * 4;
             const uint4* src = reinterpret_cast<const uint4*>(s_nodes);
             uint4* dst = reinterpret_cast<uint4*>(gNodes);
-            for (int i = threadIdx.x; i < words; i += 128) dst[i] = src[i];
+            for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
         }
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += 128) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
+        for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
     }
     PROF_FLUSH();
 }
@@ -2150,7 +2233,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
 
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
-    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(128), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
                        static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
