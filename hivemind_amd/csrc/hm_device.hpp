@@ -155,6 +155,46 @@ __device__ __forceinline__ int ufirst(int v) { return (int)__builtin_amdgcn_read
 __device__ __forceinline__ float ufirstf(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ int ulane(int v, int lane) { return (int)__builtin_amdgcn_readlane((u32)v, lane); }
 __device__ __forceinline__ float ulanef(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+// Wave-wide maximum of a 64-bit key without the LDS crossbar: four DPP steps reduce each row of 16 lanes (quad swaps,
+// half-row mirror, row mirror — any pairing works for a commutative reduction), the four row results are read out as
+// scalars.  Arg-max users pack (order-preserving image of the score) << 32 | ~index, so the larger key is the better
+// score and, among equal scores, the lower index.
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_max_step(u64 k) {
+    const u32 lo = (u32)k, hi = (u32)(k >> 32);
+    const u32 olo = (u32)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const u32 ohi = (u32)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const u64 o = ((u64)ohi << 32) | olo;
+    return o > k ? o : k;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 k) {
+#ifdef HM_NO_DPP
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_xor((int)(u32)(k >> 32), off) << 32) | (u32)__shfl_xor((int)(u32)k, off);
+        k = o > k ? o : k;
+    }
+    return ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(k >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((u32)k);
+#endif
+    k = dpp_max_step<0xB1>(k);      // quad_perm [1,0,3,2]
+    k = dpp_max_step<0x4E>(k);      // quad_perm [2,3,0,1]
+    k = dpp_max_step<0x141>(k);     // row_half_mirror
+    k = dpp_max_step<0x140>(k);     // row_mirror
+    const u32 lo = (u32)k, hi = (u32)(k >> 32);
+    u64 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = ((u64)(u32)__builtin_amdgcn_readlane(hi, 16 * i) << 32) | (u32)__builtin_amdgcn_readlane(lo, 16 * i);   // the builtin returns int: no sign extension
+
+    const u64 a = r[0] > r[1] ? r[0] : r[1], b = r[2] > r[3] ? r[2] : r[3];
+    return a > b ? a : b;
+}
+// order-preserving u32 image of a float that is not NaN (and with -0 already folded into +0): a < b <=> image(a) < image(b)
+__device__ __forceinline__ u32 float_order_bits(float f) {
+    const u32 b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_bits(u32 u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
 __device__ __forceinline__ void store_pos(hm_pos* g, const P& p) {
     u64* w = reinterpret_cast<u64*>(g);
 #pragma unroll

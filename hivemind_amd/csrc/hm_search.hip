@@ -56,7 +56,7 @@ constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown t
 constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
 constexpr int MAX_VISITS_TAB = 1 << 15;  // cpuct / PW tables
 constexpr int NLISTS = 8;                // LDS scratch move lists per wave
-constexpr int COLLECT_THREADS = 192;     // k_collect: traversal wave, classifier wave, plane-writer wave
+constexpr int COLLECT_THREADS = 256;     // k_collect: traversal wave, classifier wave, plane-writer wave, generator wave
 constexpr float Q_INIT = -1.0f;
 
 enum : uint8_t { T_UNSOLVED = 0, T_WIN = 1, T_LOSS = 2, T_DRAW = 3 };
@@ -209,6 +209,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return ufirst(v);
 }
 
+struct GenQ { int node; u32 genOff; int iA, iB; int reqSeq, ackSeq; };   // traversal wave -> generator wave (LDS)
 struct G {               // per-wave view of one game's pools
     Game* g;
     Node* nodes;
@@ -228,13 +229,39 @@ struct G {               // per-wave view of one game's pools
     // k_collect's traversal wave hands every unsolved leaf to the block's classifier wave and goes on selecting; `inflight`
     // is the leaf whose classification has not been acknowledged yet (-1: none).  Its Node must not be read before svc_wait.
     int inflight, reqSeq;
-    const int* ackSeq;
+    bool svcBusy;                    // the classifier has not finished the last request (it may still be writing the context / board image)
+    const int* ackSeq;               // requests completely finished
+    const int* typeSeq;              // requests whose terminal test is done (leaf Node final): all the tree guards need
+    // same for the generator wave: the node whose candidate generator is being refilled after a pop (its GenHdr and Node::more
+    // belong to that wave until gen_wait)
+    int genInflight, genReqSeq;
+    const int* genAckSeq;
+    GenQ* gq;
+    int nv, es;                      // nodes visited / edges scanned by this launch's descents (flushed to Game once)
 };
-// blocks until the classifier wave has finished the outstanding leaf (its writes to the leaf's Node / context are visible after)
+// blocks until the classifier wave has settled the outstanding leaf's terminal test (its writes to the leaf's Node are visible after)
 __device__ __forceinline__ void svc_wait(G& s) {
     if (s.inflight < 0) return;
-    while (__hip_atomic_load(s.ackSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.reqSeq) __builtin_amdgcn_s_sleep(1);
+    PROF_T(tsw);
+    while (__hip_atomic_load(s.typeSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.reqSeq) __builtin_amdgcn_s_sleep(1);
     s.inflight = -1;
+    PROF_ADD(19, tsw);
+}
+// blocks until the classifier wave has finished the outstanding request entirely (context record, board image, counters)
+// (behind = 1: all but the latest request)
+__device__ __forceinline__ void svc_join(G& s, int behind = 0) {
+    if (!s.svcBusy) return;
+    PROF_T(tsw);
+    while (__hip_atomic_load(s.ackSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < s.reqSeq - behind) __builtin_amdgcn_s_sleep(1);
+    if (behind == 0) { s.inflight = -1; s.svcBusy = false; }
+    PROF_ADD(22, tsw);
+}
+__device__ __forceinline__ void gen_wait(G& s) {
+    if (s.genInflight < 0) return;
+    PROF_T(tgw);
+    while (__hip_atomic_load(s.genAckSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.genReqSeq) __builtin_amdgcn_s_sleep(1);
+    s.genInflight = -1;
+    PROF_ADD(21, tgw);
 }
 __device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
 __device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : s.pl->pwRoot[v]; }
@@ -338,32 +365,33 @@ __device__ inline void gen_push(G& s, GenHdr& h, int iA, int iB) {
         }
     }
 }
-__device__ inline bool gen_next(G& s, GenHdr& h, HeapEnt* out) {   // getNext :312-328
+// refill = false: the caller hands the two successor pushes of the popped pair to another wave (k_collect's generator wave)
+__device__ inline bool gen_next(G& s, GenHdr& h, HeapEnt* out, bool refill = true) {   // getNext :312-328
     if (h.heapSize == 0) return false;
     const int lane = threadIdx.x & 63;
     HeapEnt* hp = reinterpret_cast<HeapEnt*>(s.arena + h.heap);
     const u32 n = h.heapSize;
-    // lane-parallel arg-best over the frontier: (prior desc, iA asc, iB asc) is a strict total order
-    float bp = -INFINITY; u32 bk = 0xffffffffu; int bi = -1;
+    // lane-parallel arg-best over the frontier: (prior desc, iA asc, iB asc) is a strict total order; priors are >= +0
+    u64 bestKey = 0;
+    int bi = -1;
     for (u32 base = 0; base < n; base += 64) {
         const u32 i = base + lane;
-        float pr = -INFINITY; u32 key = 0xffffffffu; int idx = -1;
-        if (i < n) { const HeapEnt e = hp[i]; pr = e.prio; key = ((u32)e.iA << 16) | (u32)e.iB; idx = (int)i; }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float op = __shfl_xor(pr, off);
-            const u32 ok = (u32)__shfl_xor((int)key, off);
-            const int oi = __shfl_xor(idx, off);
-            if (oi >= 0 && (idx < 0 || op > pr || (op == pr && ok < key))) { pr = op; key = ok; idx = oi; }
-        }
-        pr = ufirstf(pr); key = (u32)ufirst((int)key); idx = ufirst(idx);
-        if (idx >= 0 && (bi < 0 || pr > bp || (pr == bp && key < bk))) { bp = pr; bk = key; bi = idx; }
+        u64 key = 0;
+        if (i < n) { const HeapEnt e = hp[i]; key = ((u64)float_order_bits(e.prio) << 32) | (u32)~(((u32)e.iA << 16) | (u32)e.iB); }
+        const u64 top = wave_max_u64(key);
+        if (top > bestKey) { bestKey = top; bi = (int)base + (int)__builtin_ctzll(__ballot(key == top)); }   // pairs are unique
     }
+    if (bi < 0) { if (lane == 0) atomicOr(&s.g->overflow, 64); return false; }   // cannot happen (n > 0 and every key is non-zero)
+    const float bp = float_from_order_bits((u32)(bestKey >> 32));
+    const u32 bk = ~(u32)bestKey;
     const HeapEnt best{bp, (uint16_t)(bk >> 16), (uint16_t)(bk & 0xffffu)};
     h.heapSize = n - 1;
     if ((u32)bi != n - 1) hp[bi] = hp[n - 1];
     wave_fence();
-    gen_push(s, h, best.iA + 1, best.iB);
-    gen_push(s, h, best.iA, best.iB + 1);
+    if (refill) {
+        gen_push(s, h, best.iA + 1, best.iB);
+        gen_push(s, h, best.iA, best.iB + 1);
+    }
     *out = best;
     return true;
 }
@@ -558,8 +586,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
     int pending = -1;
     PROF_T(tq2);
     while (true) {
-        float bestScore = -INFINITY;
-        int bestIdx = -1;
+        u64 bestKey = 0;
         for (int base = 0; base < limit; base += 64) {
             const int i = base + lane;
             float score = -INFINITY;
@@ -581,17 +608,13 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
                     score = q + u;
                 }
             }
-            // wave arg-max of (score, lowest index).  `score > best` semantic: NaN / -inf never win.
-            float scv = ok ? score : -INFINITY;
-            int id = ok && scv > -INFINITY ? i : 0x7fffffff;
-            for (int off = 32; off > 0; off >>= 1) {
-                const float osc = __shfl_xor(scv, off);
-                const int oid = __shfl_xor(id, off);
-                if (osc > scv || (osc == scv && oid < id)) { scv = osc; id = oid; }
-            }
-            scv = ufirstf(scv); id = ufirst(id);
-            if (id != 0x7fffffff && scv > bestScore) { bestScore = scv; bestIdx = id; }
+            // wave arg-max of (score, lowest index).  `score > best` semantic: NaN / -inf never win (key 0).
+            const bool cand = ok && score > -INFINITY;             // false for NaN as well
+            const u64 key = cand ? ((u64)float_order_bits(score + 0.0f) << 32) | (u32)~(u32)i : 0ULL;
+            const u64 top = wave_max_u64(key);
+            if (top > bestKey) bestKey = top;                      // later chunks hold higher indices: a tie keeps the earlier one
         }
+        const int bestIdx = bestKey ? (int)~(u32)bestKey : -1;
         if (bestIdx < 0) return {-1, -1, false, pending};
         const int child = bestIdx < 64 ? ulane(sc.ed.child, bestIdx) : e[bestIdx].child;
         Node& cn = s.nodes[child];
@@ -741,8 +764,9 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
     p.posNode = -1;
     while (true) {
         if (cur == s.inflight) svc_wait(s);
+        if (cur == s.genInflight) gen_wait(s);
         Node n = s.nodes[cur];
-        s.g->nodesVisited++; s.g->edgesScanned += n.expanded;
+        s.nv++; s.es += n.expanded;
         if (n.type != T_UNSOLVED) break;
         if (!(n.flags & F_EXPANDED)) {
             if (!reserved) {
@@ -764,13 +788,24 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         PROF_ADD(1, tw);
         if (widen) {
             // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
+            gen_wait(s);                                          // one refill in flight
             GenHdr* gh = gen_of(s, n);
             GenHdr h = *gh;                                       // header in registers: through the pointer every field access
             HeapEnt he;                                           // is an L2 round trip that later arena stores force to repeat
             PROF_T(tg);
-            const bool got = gen_next(s, h, &he);
+            const bool async = s.genAckSeq != nullptr;
+            const bool got = gen_next(s, h, &he, !async);
             *gh = h;
-            s.nodes[cur].more = h.heapSize > 0;
+            if (got && async) {
+                // the successor pushes of the popped pair (visited-set tests, sit-rule closure, frontier growth) run on the
+                // block's generator wave; this node's generator and `more` flag are not read again before gen_wait
+                wave_fence();
+                if ((threadIdx.x & 63) == 0) { s.gq->node = cur; s.gq->genOff = n.gen; s.gq->iA = he.iA; s.gq->iB = he.iB; }
+                wave_fence();
+                s.genReqSeq++;
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&s.gq->reqSeq, s.genReqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                s.genInflight = cur;
+            } else s.nodes[cur].more = h.heapSize > 0;
             PROF_ADD(2, tg);
             if (got) {
                 const float jp = joint_prior(s, h, he.iA, he.iB, &ma, &mb);
@@ -901,12 +936,15 @@ struct WaveLds {
     u64 unavail[8];
     TrajEnt traj[MAX_TRAJ];
     // traversal wave -> classifier wave (k_collect): one leaf in flight
-    TrajEnt trajReq[MAX_TRAJ];       // the leaf's path (copied: the traversal reuses `traj` for its next descent)
-    int reqLeaf, reqTrajLen, reqCtxIdx, reqBuf, reqReserved, reqFirst;
-    int reqSeq, ackSeq, svcStop;     // reqSeq: requests posted; ackSeq: requests finished; svcStop: no more requests in this launch
+    // (two request slots, used alternately: the traversal may post the next leaf while the classifier is still writing the
+    // previous leaf's context record and board image)
+    TrajEnt trajReq[2][MAX_TRAJ];    // the leaf's path (copied: the traversal reuses `traj` for its next descent)
+    struct Req { int leaf, trajLen, ctxIdx, buf, reserved, first; } req[2];
+    int reqSeq, typeSeq, ackSeq, svcStop;   // requests posted / terminal test done / finished; svcStop: no more requests in this launch
     int reqResult;                   // outcome of the last finished request: 0 network leaf, 1 terminal, 2 dropped (not reserved)
     int svcValid;                    // network leaves of the current batch so far (= plane rows posted)
     int batchLeaf[BATCH];            // leaves of the batch being collected (same-batch collision test)
+    GenQ gq;
 };
 
 __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
@@ -926,7 +964,8 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.leafCounts = pl.leafCounts + (size_t)g * 2 * BATCH * 2;
     s.prm = &prm; s.pl = &pl;
     s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
-    s.inflight = -1; s.reqSeq = 0; s.ackSeq = nullptr;
+    s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.ackSeq = nullptr; s.typeSeq = nullptr;
+    s.genInflight = -1; s.genReqSeq = 0; s.genAckSeq = nullptr; s.gq = nullptr; s.nv = 0; s.es = 0;
     return s;
 }
 
@@ -946,7 +985,6 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     const bool aOn = (int)bd[0].stm == team, bOn = (int)bd[1].stm == (team ^ 1);
     // legal moves of the on-turn boards (R/B under-promotions already erased, utils.h:169-182): generated by the
     // plane-writer wave of k_collect while the traversal went on, fetched here
-    PROF_T(te1);
     int nReal[2];
     {
         const int* cnt = s.leafCounts + ((size_t)buf * BATCH + row) * 2;
@@ -956,7 +994,6 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
             for (int i = lane; i < nReal[b]; i += 64) L.lists[b][i] = src[(size_t)b * HM_MAX_MOVES + i];
     }
     __builtin_amdgcn_wave_barrier();
-    PROF_ADD(21, te1);
     PROF_T(te2);
     int nAct[2];
     for (int b = 0; b < 2; ++b) {
@@ -1184,11 +1221,13 @@ __device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
 // traversal never reads the Node of a leaf whose request is outstanding (svc_wait guards in scan_edges / select_and_expand /
 // canonicalize_child), one request is in flight at a time, and requests are served in order, so context slots and plane rows
 // are assigned exactly as the single-threaded loop assigns them.
-__device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv) {
+__device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv, int seq) {
     const int lane = threadIdx.x & 63;
-    const int leaf = L.reqLeaf, len = L.reqTrajLen, buf = L.reqBuf, slot = L.reqCtxIdx;
-    const bool reserved = L.reqReserved != 0;
-    const int valid = L.reqFirst ? 0 : L.svcValid;
+    const WaveLds::Req rq = L.req[seq & 1];
+    const TrajEnt* trajReq = L.trajReq[seq & 1];
+    const int leaf = rq.leaf, len = rq.trajLen, buf = rq.buf, slot = rq.ctxIdx;
+    const bool reserved = rq.reserved != 0;
+    const int valid = rq.first ? 0 : L.svcValid;
     Ctx ctx;
     ctx.leaf = leaf; ctx.trajLen = len; ctx.reserved = reserved;
     ctx.team = s.nodes[leaf].team;
@@ -1196,9 +1235,11 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     ctx.terminal = 0; ctx.termValue = 0.0f; ctx.leafHash = 0;
     const int searchPly = len - 1;
     const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
+    PROF_T(tsv);
     Path p;
     path_load(s, p, leaf);                                     // the leaf's joint position (cached at first reach)
-    path_rebuild_history(s, L.trajReq, len);                   // and the repetition keys of its path
+    path_rebuild_history(s, trajReq, len);                   // and the repetition keys of its path
+    PROF_ADD_T(15, tsv, 64);
     int endInPly = 0, result = 0, newValid = valid;
     const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
     if (to != 0) {
@@ -1210,7 +1251,13 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
         else { ctx.termValue = drawValue; ln.type = T_DRAW; ln.endInPly = 1; }
     } else if (!reserved) {
         result = 2;                                            // the traversal cancels the path's virtual losses
-    } else {
+    }
+    // the leaf's Node is final: release the traversal's tree guards before the record keeping below
+    if (lane == 0) L.reqResult = result;
+    wave_fence();
+    if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    PROF_ADD_T(24, tsv, 64);
+    if (result == 0) {
         const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
         ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
         // hm_board image in LDS for the plane writer
@@ -1222,7 +1269,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
         if (lane == 0) {
             // last move per board: deepest path move on that board, else the game's last move
             u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
-            for (int i = 1; i < len; ++i) { if (L.trajReq[i].moveA) lm[0] = L.trajReq[i].moveA; if (L.trajReq[i].moveB) lm[1] = L.trajReq[i].moveB; }
+            for (int i = 1; i < len; ++i) { if (trajReq[i].moveA) lm[0] = trajReq[i].moveA; if (trajReq[i].moveB) lm[1] = trajReq[i].moveB; }
             hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
             hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
             hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
@@ -1235,10 +1282,11 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     if (result != 2) {
         s.ctx[buf * BATCH + slot] = ctx;
         TrajEnt* dst = s.traj + (size_t)(buf * BATCH + slot) * MAX_TRAJ;
-        for (int i = lane; i < len; i += 64) dst[i] = L.trajReq[i];
+        for (int i = lane; i < len; i += 64) dst[i] = trajReq[i];
     }
-    if (lane == 0) { L.reqResult = result; L.svcValid = newValid; }
+    if (lane == 0) L.svcValid = newValid;
     wave_fence();
+    PROF_ADD_T(23, tsv, 64);
 }
 
 __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv) {
@@ -1289,16 +1337,15 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             wave_fence();
         } else {
             PROF_T(tk);
-            svc_wait(s);                                           // one request in flight
-            for (int i = lane; i < p.len; i += 64) L.trajReq[i] = L.traj[i];
-            if (lane == 0) {
-                L.reqLeaf = leaf; L.reqTrajLen = p.len; L.reqCtxIdx = nctx; L.reqBuf = buf; L.reqReserved = reserved ? 1 : 0;
-                L.reqFirst = posted ? 0 : 1;
-            }
+            svc_wait(s);                                           // one terminal test in flight
+            svc_join(s, 1);                                        // and the request slot about to be reused is free
+            const int rslot = (s.reqSeq + 1) & 1;
+            for (int i = lane; i < p.len; i += 64) L.trajReq[rslot][i] = L.traj[i];
+            if (lane == 0) L.req[rslot] = WaveLds::Req{leaf, p.len, nctx, buf, reserved ? 1 : 0, posted ? 0 : 1};
             wave_fence();
             s.reqSeq++;
             if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            s.inflight = leaf;
+            s.inflight = leaf; s.svcBusy = true;
             posted = true;
             if (!reserved) {                                       // rare: whether the context is kept depends on the terminal test
                 svc_wait(s);
@@ -1317,7 +1364,8 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             nctx++;
         }
     }
-    svc_wait(s);
+    svc_join(s);
+    gen_wait(s);
     const int valid = posted ? L.svcValid : 0;
     s.g->ctxCount[buf] = nctx;
     s.g->validCount[buf] = valid;
@@ -1470,7 +1518,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
     for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
-    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.reqSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; }
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
     const bool mirror = prm.ldsNodes != 0 && searching;
@@ -1487,9 +1535,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     PROF_ADD(9, ta);
     const int wave = threadIdx.x >> 6;
     if (wave == 0) {
-        s.ackSeq = &L.ackSeq;
+        s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq;
+        s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq;
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
         if (threadIdx.x == 0) {
+            s_game.nodesVisited += s.nv; s_game.edgesScanned += s.es;
             if (rowsNext) rowsNext[blockIdx.x] = rows;             // batch size of this game for the evaluator
             __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1510,11 +1560,32 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
                 rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (rs == seen) break;
             }
-            serve_leaf(s, s_rt, L, rootTeam, rootAdv);
-            seen = rs;
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            seen++;                                                // requests are served one by one, in order
+            serve_leaf(s, s_rt, L, rootTeam, rootAdv, seen);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (wave == 3) {
+        // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328)
+        int seen = 0;
+        for (;;) {
+            int rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rs == seen) {
+                if (!__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(1); continue; }
+                rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rs == seen) break;
+            }
+            const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
+            GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
+            GenHdr h = *gh;
+            gen_push(s, h, iA + 1, iB);
+            gen_push(s, h, iA, iB + 1);
+            *gh = h;
+            if ((threadIdx.x & 63) == 0) s.nodes[node].more = h.heapSize > 0;
+            wave_fence();
+            seen = rs;
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     } else {
         uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
         int served = 0;
@@ -1530,7 +1601,10 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
             served++;
         }
     }
+    PROF_T(tdr);
     __syncthreads();
+    PROF_ADD(25, tdr);
+    PROF_T(twb);
     if (searching) {                                               // an idle / finished game was not touched
         if (threadIdx.x == 0) s_game.listWords += L.listWords;
         if (mirror) {
@@ -1542,6 +1616,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         __syncthreads();
         for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
     }
+    PROF_ADD(26, twb);
     PROF_FLUSH();
 }
 

@@ -32,8 +32,8 @@ res = sp.run()
 fn(buf.ctypes.data, 0)
 names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "select_child(puct)", "jb_make", "canonicalize_child",
          "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total", "path_reset", "process: backup_batch",
-         "classify: legal_counts", "classify: checkmate x2", "classify: draw", "classify: waiting-board mate", "puct: pass 1", "puct: arg-max loop",
-         "expand: movegen", "expand: softmax", "expand: rank sort", "expand: generator init", "planes: hash+store", "planes: write", "position_child: path_load", "position_child: path_store", "scan_edges"]
+         "classifier wave: load + history", "classify: checkmate x2", "classify: draw", "classify: waiting-board mate", "wait: classifier wave", "puct: arg-max loop",
+         "wait: generator wave", "wait: classifier (join)", "classifier wave: request total", "classifier wave: until type ack", "k_collect: drain (block join)", "k_collect: write-back", "position_child: path_load", "position_child: path_store", "scan_edges"]
 it = res.search_iterations
 print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
 if int(buf[31]):
