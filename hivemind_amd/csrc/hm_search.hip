@@ -929,8 +929,12 @@ struct WaveLds {
     u64 board[BATCH][26];    // hm_board images of this batch's network leaves, handed to the plane-writer wave
     int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
     int postBuf;             // which of the two batches (0/1) the posted leaves belong to
+    int postRow[BATCH];      // plane row of each posted image (ring slot = post number & 7)
+    int servedCnt;           // posts the plane-writer wave has finished (flow control of the image ring)
+    int servedCntB;          // posts whose board-B move list the generator wave has finished
+    int postCount;           // images posted so far in this launch (classifier wave's counter)
     int listWords;           // wave 1: move-list words written this launch (traffic accounting)
-    u32 helperLists[1][HM_MAX_MOVES];   // wave 1: legal list of the leaf board being served
+    u32 helperLists[2][HM_MAX_MOVES];   // plane-writer wave / generator wave: legal list of the leaf board being served
     u64 pmask[HM_NB_PLANES + 6];
     uint32_t pval[HM_NB_PLANES + 6];
     u64 unavail[8];
@@ -1056,7 +1060,12 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         }
     }
     // JointCandidateGenerator::initialize (joint_action.h:195-278): rank sort by (prior desc, index asc)
-    const u32 genOff = arena_alloc(s, sizeof(GenHdr));
+    // one bump allocation for the header, both sorted move / prior arrays, the frontier, the visited list and the first four
+    // edge slots (seven round trips to the game's arena counter otherwise)
+    auto units = [](u32 bytes) { return (bytes + 7) >> 3; };
+    const u32 uHdr = units(sizeof(GenHdr)), uA = units((u32)nAct[0] * 4), uB = units((u32)nAct[1] * 4);
+    const u32 uHeap = units(16 * 8), uVis = units(32 * 4), uEdges = units(4 * sizeof(Edge));
+    const u32 genOff = arena_alloc(s, (uHdr + 2 * uA + 2 * uB + uHeap + uVis + uEdges) * 8);
     if (!genOff) return;
     GenHdr h;
     h.nA = nAct[0]; h.nB = nAct[1];
@@ -1064,13 +1073,11 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     h.aCan = aOn && nReal[0] > 0; h.bCan = bOn && nReal[1] > 0;
     h.pad[0] = h.pad[1] = h.pad[2] = 0;
     u32 offM[2], offP[2];
-    for (int b = 0; b < 2; ++b) {
-        offM[b] = arena_alloc(s, (u32)nAct[b] * 4);
-        offP[b] = arena_alloc(s, (u32)nAct[b] * 4);
-    }
-    h.heapCap = 16; h.heapSize = 0; h.heap = arena_alloc(s, h.heapCap * 8);
-    h.visCap = 32; h.visSize = 0; h.visited = arena_alloc(s, h.visCap * 4);
-    if (!offM[0] || !offP[0] || !offM[1] || !offP[1] || !h.heap || !h.visited) return;
+    offM[0] = genOff + uHdr; offP[0] = offM[0] + uA;
+    offM[1] = offP[0] + uA;  offP[1] = offM[1] + uB;
+    h.heapCap = 16; h.heapSize = 0; h.heap = offP[1] + uB;
+    h.visCap = 32; h.visSize = 0; h.visited = h.heap + uHeap;
+    const u32 firstEdges = h.visited + uVis;
     PROF_T(te3);
     for (int b = 0; b < 2; ++b) {
         const int n = nAct[b];
@@ -1102,6 +1109,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         u32 ma, mb;
         const float jp = joint_prior(s, h, he.iA, he.iB, &ma, &mb);
         const int child = node_alloc(s, leaf.team ^ 1, leaf.depth + 1);
+        if (leaf.edgeCap == 0) { leaf.edges = firstEdges; leaf.edgeCap = 4; }    // the slots allocated with the generator block
         Edge* slot = child >= 0 ? edge_append(s, leaf) : nullptr;
         if (slot) {
             *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 0, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
@@ -1240,6 +1248,31 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     path_load(s, p, leaf);                                     // the leaf's joint position (cached at first reach)
     path_rebuild_history(s, trajReq, len);                   // and the repetition keys of its path
     PROF_ADD_T(15, tsv, 64);
+    // The plane-writer wave starts on this leaf now, into row `valid`, while the terminal test below runs: a leaf that turns out
+    // terminal (or is dropped) simply leaves `valid` where it is and the next network leaf overwrites the row (posts are served
+    // in order).  Everything the planes and the move lists need is known here.
+    if (reserved) {
+        const int np_ = L.postCount;
+        while (np_ - min(__hip_atomic_load(&L.servedCnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP),
+                         __hip_atomic_load(&L.servedCntB, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= BATCH) __builtin_amdgcn_s_sleep(1);   // ring slot free
+        hm_board* hb = reinterpret_cast<hm_board*>(L.board[np_ & (BATCH - 1)]);
+        const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
+        store_pos(&hb->pos[0], p.jb.bd[0]);                   // every lane writes the same words
+        store_pos(&hb->pos[1], p.jb.bd[1]);
+        if (lane == 0) {
+            // last move per board: deepest path move on that board, else the game's last move
+            u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
+            for (int i = 1; i < len; ++i) { if (trajReq[i].moveA) lm[0] = trajReq[i].moveA; if (trajReq[i].moveB) lm[1] = trajReq[i].moveB; }
+            hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
+            hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
+            hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
+            L.postRow[np_ & (BATCH - 1)] = valid;
+            L.postBuf = buf;
+            L.postCount = np_ + 1;
+        }
+        wave_fence();
+        if (lane == 0) __hip_atomic_store(&L.posted, np_ + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     int endInPly = 0, result = 0, newValid = valid;
     const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
     if (to != 0) {
@@ -1260,23 +1293,6 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     if (result == 0) {
         const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
         ctx.leafHash = board_hash_key(p.jb.bd[0], p.jb.bd[1], hist_of(p.jb, 0), hist_of(p.jb, 1), leafAdv, rt.zob.time_adv);
-        // hm_board image in LDS for the plane writer
-        wave_fence();
-        hm_board* hb = reinterpret_cast<hm_board*>(L.board[valid]);
-        const int rcA = repetition_count(hist_of(p.jb, 0)), rcB = repetition_count(hist_of(p.jb, 1));
-        store_pos(&hb->pos[0], p.jb.bd[0]);                   // every lane writes the same words
-        store_pos(&hb->pos[1], p.jb.bd[1]);
-        if (lane == 0) {
-            // last move per board: deepest path move on that board, else the game's last move
-            u32 lm[2] = {s.g->lastMove[0], s.g->lastMove[1]};
-            for (int i = 1; i < len; ++i) { if (trajReq[i].moveA) lm[0] = trajReq[i].moveA; if (trajReq[i].moveB) lm[1] = trajReq[i].moveB; }
-            hb->last_move[0] = lm[0]; hb->last_move[1] = lm[1];
-            hb->rep_count[0] = (uint8_t)(rcA > 3 ? 3 : rcA); hb->rep_count[1] = (uint8_t)(rcB > 3 ? 3 : rcB);
-            hb->team = ctx.team; hb->time_adv = ctx.sit; hb->reserved = 0;
-        }
-        wave_fence();
-        // the planes are written by the third wave of the block
-        if (lane == 0) { L.postBuf = buf; __hip_atomic_store(&L.posted, valid + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
         newValid = valid + 1;
     }
     if (result != 2) {
@@ -1461,32 +1477,30 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
 
 // Legal move lists of network leaf `slot` (both boards, lane 0 -> A, lane 1 -> B, R/B under-promotions erased as
 // utils.h:169-182) from its hm_board image: the expansion in k_process reads them instead of generating.
-__device__ inline void leaf_move_lists(const Pools& pl, const RulesTab& rt, WaveLds& L, int g, int slot) {
+__device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveLds& L, int g, int img, int slot, int b) {
     const int lane = threadIdx.x & 63;
-    const hm_board* hb = reinterpret_cast<const hm_board*>(L.board[slot]);
+    const hm_board* hb = reinterpret_cast<const hm_board*>(L.board[img]);
     const int buf = L.postBuf, team = hb->team;
     const size_t base = (((size_t)g * 2 + buf) * BATCH + slot) * 2;
-    for (int b = 0; b < 2; ++b) {
-        P p;
-        load_pos(p, &hb->pos[b]);
-        const bool on = b == 0 ? (int)p.stm == team : (int)p.stm == (team ^ 1);
-        int kept = 0;
-        if (on) {
-            u32* list = L.helperLists[0];
-            const int n = gen_legal_wave(rt.att, p, list);          // wave-cooperative, reference list order
-            u32* dst = pl.leafMoves + (base + b) * HM_MAX_MOVES;
-            for (int c0 = 0; c0 < n; c0 += 64) {                    // order-preserving erase of the R/B under-promotions
-                const int i = c0 + lane;
-                const u32 m = i < n ? list[i] : 0u;
-                const bool keep = i < n && !((m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP));
-                const u64 km = __ballot(keep);
-                if (keep) dst[kept + __popcll(km & ((1ULL << lane) - 1ULL))] = m;
-                kept += __popcll(km);
-            }
-            __builtin_amdgcn_wave_barrier();
+    P p;
+    load_pos(p, &hb->pos[b]);
+    const bool on = b == 0 ? (int)p.stm == team : (int)p.stm == (team ^ 1);
+    int kept = 0;
+    if (on) {
+        u32* list = L.helperLists[b];
+        const int n = gen_legal_wave(rt.att, p, list);          // wave-cooperative, reference list order
+        u32* dst = pl.leafMoves + (base + b) * HM_MAX_MOVES;
+        for (int c0 = 0; c0 < n; c0 += 64) {                    // order-preserving erase of the R/B under-promotions
+            const int i = c0 + lane;
+            const u32 m = i < n ? list[i] : 0u;
+            const bool keep = i < n && !((m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP));
+            const u64 km = __ballot(keep);
+            if (keep) dst[kept + __popcll(km & ((1ULL << lane) - 1ULL))] = m;
+            kept += __popcll(km);
         }
-        if (lane == 0) { pl.leafCounts[base + b] = kept; L.listWords += kept; }
+        __builtin_amdgcn_wave_barrier();
     }
+    if (lane == 0) { pl.leafCounts[base + b] = kept; atomicAdd(&L.listWords, kept); }
 }
 
 // Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
@@ -1518,7 +1532,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
     for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
-    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
     const bool mirror = prm.ldsNodes != 0 && searching;
@@ -1566,25 +1580,37 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         }
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 3) {
-        // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328)
-        int seen = 0;
+        // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328) and, between
+        // them, the board-B legal move list of every posted leaf image (the plane-writer wave does the planes and board A)
+        int seen = 0, servedB = 0;
         for (;;) {
-            int rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (rs == seen) {
-                if (!__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(1); continue; }
-                rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (rs == seen) break;
+            const int rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rs != seen) {
+                const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
+                GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
+                GenHdr h = *gh;
+                gen_push(s, h, iA + 1, iB);
+                gen_push(s, h, iA, iB + 1);
+                *gh = h;
+                if ((threadIdx.x & 63) == 0) s.nodes[node].more = h.heapSize > 0;
+                wave_fence();
+                seen = rs;
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
             }
-            const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
-            GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
-            GenHdr h = *gh;
-            gen_push(s, h, iA + 1, iB);
-            gen_push(s, h, iA, iB + 1);
-            *gh = h;
-            if ((threadIdx.x & 63) == 0) s.nodes[node].more = h.heapSize > 0;
-            wave_fence();
-            seen = rs;
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (servedB < posted) {
+                const int img = servedB & (BATCH - 1);
+                leaf_move_list(pl, s_rt, L, blockIdx.x, img, L.postRow[img], 1);
+                servedB++;
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+            // nothing to do: leave once the traversal has stopped (no more refills) and the classifier is done (no more images)
+            if (__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) && __hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+                && __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen
+                && __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == servedB) break;
+            __builtin_amdgcn_s_sleep(1);
         }
     } else {
         uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
@@ -1596,9 +1622,11 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
                 posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (served >= posted) break;
             }
-            write_planes_f16(s_rt, L.board[served], reinterpret_cast<uint4*>(dst + (size_t)served * HM_PLANE_VALUES), L.pmask, L.pval);
-            leaf_move_lists(pl, s_rt, L, blockIdx.x, served);
+            const int img = served & (BATCH - 1), row = L.postRow[img];
+            write_planes_f16(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
+            leaf_move_list(pl, s_rt, L, blockIdx.x, img, row, 0);
             served++;
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     PROF_T(tdr);
