@@ -20,6 +20,8 @@ from ._lib import (BOARD_DTYPE, POS_DTYPE, DT_F16, DT_F32, DT_U8, MAX_MOVES, NB_
 from .search import SearchEngine, SearchConfig, default_config, rules_probe  # noqa: E402,F401
 from .selfplay import (SelfPlay, SelfPlayConfig, default_selfplay_config, gather_records, read_hvm4,  # noqa: E402,F401
                        write_chunk)
+from .tournament import (Tournament, TournamentConfig, TournamentResult, default_tournament_config,  # noqa: E402,F401
+                         move_uci, statistics as tournament_statistics)
 
 _TORCH_DT = {DT_F16: torch.float16, DT_F32: torch.float32, DT_U8: torch.uint8}
 _NAME_DT = {"f16": DT_F16, "f32": DT_F32, "u8": DT_U8, torch.float16: DT_F16,

@@ -124,6 +124,7 @@ struct Game {
     int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
     int listWords;                      // leaf move-list words written by the helper wave (traffic accounting)
     int live;                           // slot holds a game (set by k_set_games); dead slots are skipped by every kernel
+    int pwSel;                          // progressive-widening profile of the side searching now: 0 = the engine's tables, 1 = the alternate pair (hm_sp_set_pw_profiles)
 };
 
 struct Params {          // device-visible configuration + pool geometry
@@ -151,6 +152,8 @@ struct Pools {
     const float* cpuctTab;   // [MAX_VISITS_TAB]
     const int* pwRoot;       // [MAX_VISITS_TAB]
     const int* pwNode;
+    const int* pwRootAlt;    // second schedule (tournaments give each network its own PW coefficient, tournament.h:30-41)
+    const int* pwNodeAlt;
     const RulesTab* rules;
     const int* polNormal;    // [2][64][64][2]
     const int* polDrop;      // [2][64][8]
@@ -264,8 +267,8 @@ __device__ __forceinline__ void gen_wait(G& s) {
     PROF_ADD(21, tgw);
 }
 __device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
-__device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : s.pl->pwRoot[v]; }
-__device__ __forceinline__ int pw_node_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwNode[v] : s.pl->pwNode[v]; }
+__device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : (s.g->pwSel ? s.pl->pwRootAlt : s.pl->pwRoot)[v]; }
+__device__ __forceinline__ int pw_node_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwNode[v] : (s.g->pwSel ? s.pl->pwNodeAlt : s.pl->pwNode)[v]; }
 __device__ __forceinline__ Edge* edges_of(const G& s, const Node& n) { return reinterpret_cast<Edge*>(s.arena + n.edges); }
 __device__ __forceinline__ GenHdr* gen_of(const G& s, const Node& n) { return reinterpret_cast<GenHdr*>(s.arena + n.gen); }
 
@@ -1531,7 +1534,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     Node* const gNodes = s.nodes;
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
     stage_table(&s_rt, pl.rules);
-    for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pl.pwRoot[i], 65535); s_pwNode[i] = (uint16_t)min(pl.pwNode[i], 65535); }
+    {
+        const bool alt = gGame->pwSel != 0;                      // this game's progressive-widening profile
+        const int* pwr = alt ? pl.pwRootAlt : pl.pwRoot;
+        const int* pwn = alt ? pl.pwNodeAlt : pl.pwNode;
+        for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
+    }
     if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
@@ -1940,7 +1948,12 @@ __global__ __launch_bounds__(64) void k_set_games(Pools pl, Params prm, const hm
         gm.hlen[b] = 1;
         gm.prefix[b] = mix_hash(HISTORY_HASH_SEED, k);
     }
-    gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0; gm.live = 1;
+    gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0; gm.live = 1; gm.pwSel = 0;
+}
+
+__global__ void k_set_pw_sel(Pools pl, int n, const uint8_t* sel) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) pl.games[g].pwSel = sel[g] ? 1 : 0;
 }
 
 // game state export: hm_board (for record planes / host bookkeeping) + terminal flags
@@ -2148,6 +2161,8 @@ struct hm_sp {
     int* d_term;
     float alpha = 0.0f, eps = 0.0f;
     std::vector<u64> h_rootHash;
+    float pwExponent = 0.4f, altPw = -1.0f, altRootPw = -1.0f;
+    int *d_pwRootAlt = nullptr, *d_pwNodeAlt = nullptr;
 };
 
 #define HIPCHK(expr)                                                                              \
@@ -2262,6 +2277,14 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     (void)hipMemcpy(dpr, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
     (void)hipMemcpy(dpn, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
     pl.cpuctTab = dcp; pl.pwRoot = dpr; pl.pwNode = dpn;
+    // the alternate schedule has its own tables from the start (kernel arguments captured in a HIP graph keep these pointers);
+    // hm_sp_set_pw_profiles rewrites their contents
+    rc |= dalloc(sp, &sp->d_pwRootAlt, MAX_VISITS_TAB); rc |= dalloc(sp, &sp->d_pwNodeAlt, MAX_VISITS_TAB);
+    if (rc) { hm_sp_destroy(sp); return rc; }
+    (void)hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    pl.pwRootAlt = sp->d_pwRootAlt; pl.pwNodeAlt = sp->d_pwNodeAlt;
+    sp->pwExponent = c.pw_exponent;
     pl.rules = g_rules_dev; pl.polNormal = g_polN_dev; pl.polDrop = g_polD_dev;
     RootOut& ro = sp->ro;
     ro.maxEdges = sp->maxEdges;
@@ -2276,6 +2299,31 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     if (rc) { hm_sp_destroy(sp); return rc; }
     sp->h_rootHash.resize(2 * G_);
     *out = sp;
+    return 0;
+}
+
+// Progressive-widening schedule per game slot (TournamentConfig::searchConfigFor, tournament.h:34-41: each network searches
+// with its own coefficient, used for root and interior nodes alike).  profiles[g] != 0 selects the alternate schedule built
+// from (alt_pw_coefficient, alt_root_pw_coefficient); it stays until the next call or hm_sp_set_games.
+int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw_coefficient, const uint8_t* profiles) {
+    if (!sp || !profiles) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (!(alt_pw_coefficient > 0.0f) || !(alt_root_pw_coefficient > 0.0f) || !std::isfinite(alt_pw_coefficient) || !std::isfinite(alt_root_pw_coefficient))
+        return hm_fail(HM_ERR_INVALID, "PW coefficients must be positive and finite");
+    if (alt_pw_coefficient != sp->altPw || alt_root_pw_coefficient != sp->altRootPw) {
+        std::vector<int> pr(MAX_VISITS_TAB), pn(MAX_VISITS_TAB);
+        for (int v = 0; v < MAX_VISITS_TAB; ++v) {
+            auto allowed = [&](float coef) { return v <= 0 ? 1 : (int)std::ceil(coef * std::pow((float)v, sp->pwExponent)); };
+            pr[v] = allowed(alt_root_pw_coefficient);
+            pn[v] = allowed(alt_pw_coefficient);
+        }
+        HIPCHK(hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice));
+        sp->altPw = alt_pw_coefficient; sp->altRootPw = alt_root_pw_coefficient;
+    }
+    HIPCHK(hipMemcpy(sp->d_mask, profiles, sp->nGames, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_pw_sel, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, sp->d_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
     return 0;
 }
 

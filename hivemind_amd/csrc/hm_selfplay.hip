@@ -23,7 +23,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <cerrno>
+#include <filesystem>
 #include <fstream>
+#include <iomanip>
+#include <sstream>
 #include <sys/stat.h>
 #include <map>
 #include <numeric>
@@ -129,7 +132,34 @@ struct hm_selfplay {
     hipEvent_t gFork = nullptr, gJoin = nullptr;
     int graphState = 0;                            // 0 not tried, 1 ready, -1 unavailable (eager loop)
     int32_t* d_rows[2] = {nullptr, nullptr};   // per game slot: plane rows written into planes[k] (ragged evaluator batch)
+    // second network (tournaments: contender = io.net, baseline = net2): every slot's search is evaluated by the network of
+    // the team to move, so each iteration launches both forwards over disjoint row sets
+    const hm_net* net2 = nullptr;
+    uint8_t* d_netSel = nullptr;               // per slot: 0 = io.net, 1 = net2 (fixed during a search)
+    int32_t* d_rowsNet[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [net][plane buffer]: d_rows masked by d_netSel
 };
+
+__global__ void k_split_rows(const int32_t* rows, const uint8_t* sel, int32_t* rows0, int32_t* rows1, int n) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) { const int r = rows[g]; const bool second = sel[g] != 0; rows0[g] = second ? 0 : r; rows1[g] = second ? r : 0; }
+}
+// collect(next) with the per-game row counts the evaluator launches need
+static int collect_rows(hm_selfplay* s, int next) {
+    if (int rc = hm_sp_collect_counted(s->sp, s->io.planes[next], s->d_rows[next], s->sT)) return rc;
+    if (s->net2) {
+        hipLaunchKernelGGL(k_split_rows, dim3((s->G + 63) / 64), dim3(64), 0, s->sT, s->d_rows[next], s->d_netSel, s->d_rowsNet[0][next], s->d_rowsNet[1][next], s->G);
+        if (hipGetLastError() != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "k_split_rows launch failed");
+    }
+    return 0;
+}
+// forward(cur) on the network stream: one launch, or one per network over its slots' rows
+static int forward_rows(hm_selfplay* s, int which, void** h, bool allRows) {
+    if (!s->net2)
+        return hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8, h[0], h[1], h[2], h[3], h[4], s->sN);
+    if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, s->d_rowsNet[0][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+    return hm_net_forward_groups(s->net2, s->io.planes[which], s->G * 8, s->d_rowsNet[1][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN);
+}
+
 
 static bool start_game(hm_selfplay* s, Slot& sl, hm_board& out) {
     const hm_selfplay_config& c = s->cfg;
@@ -223,9 +253,8 @@ static int enqueue_iteration(hm_selfplay* s, int which, int parity, hipEvent_t f
     void** h = hv[parity];
     (void)hipEventRecord(fork, s->sT);             // forward(i) runs behind process(i-1), beside collect(i)
     (void)hipStreamWaitEvent(s->sN, fork, 0);
-    if (int rc = hm_sp_collect_counted(s->sp, s->io.planes[1 - which], s->d_rows[1 - which], s->sT)) return rc;
-    if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8,
-                                       h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+    if (int rc = collect_rows(s, 1 - which)) return rc;
+    if (int rc = forward_rows(s, which, h, allRows)) return rc;
     (void)hipEventRecord(join, s->sN);
     (void)hipStreamWaitEvent(s->sT, join, 0);
     return hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT);
@@ -282,6 +311,7 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     if (native) {
         (void)hipMemsetAsync(s->d_rows[0], 0, sizeof(int32_t) * s->G, nullptr);      // nothing collected yet for this search
         (void)hipMemsetAsync(s->d_rows[1], 0, sizeof(int32_t) * s->G, nullptr);
+        if (s->net2) for (int k = 0; k < 4; ++k) (void)hipMemsetAsync(s->d_rowsNet[k >> 1][k & 1], 0, sizeof(int32_t) * s->G, nullptr);
         (void)hipDeviceSynchronize();              // the prologue ran on the null stream
     }
     // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
@@ -330,7 +360,7 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
                               {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
             void** h = hv[iters & 1];
             if (timed) (void)hipEventRecord(e[0], s->sT);
-            if (int rc = hm_sp_collect_counted(s->sp, s->io.planes[1 - which], s->d_rows[1 - which], s->sT)) return rc;
+            if (int rc = collect_rows(s, 1 - which)) return rc;
             if (timed) (void)hipEventRecord(e[1], s->sT);
             // planes[which] were completed by the previous iteration's collect.  The forward could start
             // right after it, but measured on MI355X it then shares CUs with k_process (8-wave blocks,
@@ -338,8 +368,7 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             // forward is ordered behind process(i-1) and overlaps only collect(i).
             if (iters > 0) (void)hipStreamWaitEvent(s->sN, yPrev[1], 0);
             if (timed) (void)hipEventRecord(e[2], s->sN);
-            if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8,
-                                               h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
+            if (int rc = forward_rows(s, which, h, allRows)) return rc;
             if (timed) (void)hipEventRecord(e[3], s->sN);
             (void)hipEventRecord(y[0], s->sN);
             (void)hipStreamWaitEvent(s->sT, y[0], 0);
@@ -426,6 +455,8 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->d_u8) (void)hipFree(s->d_u8);
     if (s->d_rows[0]) (void)hipFree(s->d_rows[0]);
     if (s->d_rows[1]) (void)hipFree(s->d_rows[1]);
+    if (s->d_netSel) (void)hipFree(s->d_netSel);
+    for (int k = 0; k < 4; ++k) if (s->d_rowsNet[k >> 1][k & 1]) (void)hipFree(s->d_rowsNet[k >> 1][k & 1]);
     if (s->sT) (void)hipStreamDestroy(s->sT);
     if (s->sN && s->sN != s->sT) (void)hipStreamDestroy(s->sN);
     if (s->hActive) (void)hipHostFree(s->hActive);
@@ -725,6 +756,406 @@ int hm_hvm4_write_chunk(const char* path, const uint8_t* records, uint64_t nbyte
     if (!f) return hm_fail(HM_ERR_INVALID, "Failed to finalize " + tmp);
     if (std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return hm_fail(HM_ERR_INVALID, std::string("Unable to publish ") + path); }
     return 0;
+}
+
+// =======================================================================================
+// paired network tournament (tools/tournament.cc:328-465) on the lockstep rollout core
+// =======================================================================================
+}  // extern "C"
+
+namespace {
+
+struct TGame {                      // one finished (or running) tournament game
+    int winner = -1;                // -1 none, HM_WHITE / HM_BLACK
+    int termination = 3;            // 0 checkmate, 1 no legal action, 2 draw, 3 macro-ply limit
+    std::vector<std::string> actions;
+    bool done = false;
+};
+struct TSlot {
+    bool active = false;
+    size_t gameIndex = 0, macroPly = 0;
+    int contenderTeam = 0, team = 0;
+    bool adv = false;
+};
+const char* const kTermination[4] = {"checkmate", "no legal action", "draw", "macro-ply limit"};
+
+uint64_t tournament_seed(uint64_t seed, uint64_t value) {   // tournament.cc:22-27
+    value += 0x9e3779b97f4a7c15ULL;
+    value = (value ^ (value >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    value = (value ^ (value >> 27)) * 0x94d049bb133111ebULL;
+    return seed ^ (value ^ (value >> 31));
+}
+// UCI::move (Fairy-Stockfish/src/stubs.cpp:21-59) through Board::uci_move (board.h:340-350) for this variant
+std::string uci_move(hm_move m) {
+    if (m == 0) return "pass";
+    auto sq = [](int q) { std::string r; r += char('a' + (q & 7)); r += char('1' + (q >> 3)); return r; };
+    const int from = (int)((m >> 6) & 63);
+    int to = (int)(m & 63);
+    const uint32_t mt = m & (15u << 12);
+    if (mt == HM_MT_CASTLING) to = (to > from ? 6 : 2) + (from & 56);      // king -> rook square is printed king -> g / c file
+    std::string r;
+    if (mt == HM_MT_DROP) { r += " PNBRQ"[(m >> 16) & 7]; r += '@'; }
+    else r += sq(from);
+    r += sq(to);
+    if (mt == HM_MT_PROMOTION) r += " pnbrq"[(m >> 16) & 7];
+    return r;
+}
+void fill_statistics(hm_tournament_result& r, const std::vector<double>& pairScores) {   // tournament.cc:247-326
+    const uint64_t games = r.contender_wins + r.baseline_wins + r.draws;
+    r.pairs = pairScores.size();
+    r.contender_score = games == 0 ? 0.0 : ((double)r.contender_wins + 0.5 * (double)r.draws) / (double)games;
+    const double score = r.contender_score;
+    r.has_elo = !(games == 0 || score <= 0.0 || score >= 1.0);
+    r.contender_elo = r.has_elo ? 400.0 * std::log10(score / (1.0 - score)) : 0.0;
+    r.paired_method = pairScores.size() >= 2;
+    r.has_score_ci = games != 0;
+    r.score_ci[0] = r.score_ci[1] = 0.0;
+    if (r.has_score_ci) {
+        constexpr double z = 1.959963984540054;
+        if (pairScores.size() >= 2) {
+            const double count = (double)pairScores.size();
+            const double mean = std::accumulate(pairScores.begin(), pairScores.end(), 0.0) / count;
+            const double squaredError = std::accumulate(pairScores.begin(), pairScores.end(), 0.0,
+                [mean](double total, double sc) { const double d = sc - mean; return total + d * d; });
+            const double sampleVariance = squaredError / (count - 1.0);
+            const double margin = z * std::sqrt(sampleVariance / count);
+            r.score_ci[0] = std::max(0.0, mean - margin); r.score_ci[1] = std::min(1.0, mean + margin);
+        } else {
+            const double count = (double)games;
+            const double denominator = 1.0 + z * z / count;
+            const double center = (score + z * z / (2.0 * count)) / denominator;
+            const double margin = z * std::sqrt(score * (1.0 - score) / count + z * z / (4.0 * count * count)) / denominator;
+            r.score_ci[0] = std::max(0.0, center - margin); r.score_ci[1] = std::min(1.0, center + margin);
+        }
+    }
+    r.has_elo_ci = r.has_score_ci && !(r.score_ci[0] <= 0.0 || r.score_ci[1] >= 1.0);
+    auto score_to_elo = [](double sc) { return 400.0 * std::log10(sc / (1.0 - sc)); };
+    r.elo_ci[0] = r.has_elo_ci ? score_to_elo(r.score_ci[0]) : 0.0;
+    r.elo_ci[1] = r.has_elo_ci ? score_to_elo(r.score_ci[1]) : 0.0;
+}
+
+}  // namespace
+
+struct hm_tournament {
+    hm_tournament_config cfg;
+    hm_selfplay* core = nullptr;    // lockstep engine: game slots, search pools, streams, captured iteration graph
+    std::vector<TSlot> slots;
+    std::vector<TGame> games;
+    std::vector<uint8_t> acting;    // per slot: 1 = the contender's network evaluates the search in flight
+    std::vector<double> pairScores;
+    size_t nextGame = 0;
+    hm_tournament_result res{};
+};
+
+static bool tournament_start(hm_tournament* t, TSlot& sl, hm_board& out) {
+    if (t->nextGame >= t->cfg.games) { sl.active = false; return false; }
+    sl = TSlot();
+    sl.active = true;
+    sl.gameIndex = t->nextGame++;
+    const size_t pairIndex = sl.gameIndex / 2;
+    sl.contenderTeam = sl.gameIndex % 2 == 0 ? HM_WHITE : HM_BLACK;          // tournament.cc:371-376
+    sl.team = pairIndex % 2 == 0 ? HM_WHITE : HM_BLACK;
+    sl.adv = false;
+    hm_board_startpos(&out);
+    out.team = (uint8_t)sl.team;
+    out.time_adv = 0;
+    return true;
+}
+
+static int tournament_run_impl(hm_tournament* t) {
+    hm_selfplay* s = t->core;
+    const hm_tournament_config& c = t->cfg;
+    const int G = s->G;
+    const int E = hm_sp_max_edges(s->sp);
+    std::vector<hm_board> boards(G), init(G);
+    std::vector<int> flags(G), counts(G), target(G), info((size_t)G * HM_SP_INFO_INTS), visits((size_t)G * E);
+    std::vector<uint8_t> mask(G), profile(G), applyMask(G);
+    std::vector<hm_move> mA((size_t)G * E), mB((size_t)G * E), actA(G), actB(G);
+    std::vector<float> rootQ(G);
+    std::vector<uint64_t> seeds(G);
+    t->games.assign(c.games, TGame());
+    t->slots.assign(G, TSlot());
+    t->acting.assign(G, 0);
+    t->nextGame = 0;
+    auto finish = [&](TSlot& sl, int winner, int termination) {
+        TGame& g = t->games[sl.gameIndex];
+        g.winner = winner; g.termination = termination; g.done = true;
+        sl.active = false;
+    };
+    for (int g = 0; g < G; ++g) { hm_board_startpos(&init[g]); mask[g] = tournament_start(t, t->slots[g], init[g]) ? 1 : 0; }
+    if (int rc = hm_sp_set_games(s->sp, init.data(), mask.data())) return rc;
+    while (true) {
+        // top of the macro-ply loop (tournament.cc:383-392) and its exit (:367, :417-422): checkmate, draw, macro-ply limit
+        bool restarted = true;
+        while (restarted) {
+            restarted = false;
+            if (int rc = hm_sp_game_state(s->sp, boards.data(), flags.data(), s->d_boards)) return rc;
+            std::fill(mask.begin(), mask.end(), 0);
+            for (int g = 0; g < G; ++g) {
+                TSlot& sl = t->slots[g];
+                if (!sl.active) continue;
+                bool done = true;
+                if (flags[g] & 1) finish(sl, sl.team ^ 1, 0);
+                else if (flags[g] & 2) finish(sl, -1, 2);
+                else if (sl.macroPly >= c.max_macro_plies) finish(sl, -1, 3);
+                else done = false;
+                if (done && tournament_start(t, sl, init[g])) { mask[g] = 1; restarted = true; }
+            }
+            if (restarted) if (int rc = hm_sp_set_games(s->sp, init.data(), mask.data())) return rc;
+        }
+        bool any = false;
+        for (int g = 0; g < G; ++g) { mask[g] = t->slots[g].active; any |= mask[g] != 0; }
+        if (!any) break;
+        // one search per live game by the network of the team to move (:394-409)
+        for (int g = 0; g < G; ++g) {
+            const TSlot& sl = t->slots[g];
+            const bool contenderActing = sl.active && sl.team == sl.contenderTeam;
+            t->acting[g] = contenderActing ? 1 : 0;
+            profile[g] = contenderActing ? 0 : 1;                              // schedule 0 = contender's PW coefficient, 1 = baseline's
+            target[g] = (int)c.nodes;
+            seeds[g] = sl.active ? tournament_seed(c.seed, (sl.gameIndex / 2) * c.max_macro_plies + sl.macroPly) : 0;
+        }
+        if (int rc = hm_sp_set_pw_profiles(s->sp, c.baseline_pw_coefficient, c.baseline_pw_coefficient, profile.data())) return rc;
+        if (s->d_netSel && hipMemcpy(s->d_netSel, profile.data(), (size_t)G, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
+        if (int rc = hm_sp_begin_search(s->sp, target.data(), seeds.data(), c.dirichlet_alpha, c.dirichlet_epsilon, mask.data())) return rc;
+        if (int rc = run_search_lockstep(s, (int)c.nodes)) return rc;
+        if (int rc = hm_sp_root_stats(s->sp, counts.data(), mA.data(), mB.data(), visits.data(), nullptr, nullptr, rootQ.data(), info.data(), E)) return rc;
+        std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0); std::fill(applyMask.begin(), applyMask.end(), 0);
+        for (int g = 0; g < G; ++g) {
+            if (!mask[g]) continue;
+            TSlot& sl = t->slots[g];
+            if (info[(size_t)g * HM_SP_INFO_INTS + 8]) return hm_fail(HM_ERR_OVERFLOW, "search pool overflow in game slot " + std::to_string(g) + " (flags " + std::to_string(info[(size_t)g * HM_SP_INFO_INTS + 8]) + ")");
+            t->res.searched_positions += 1;
+            const int n = counts[g];
+            if (n == 0) { finish(sl, sl.team ^ 1, 1); continue; }                     // no legal action (:403-407)
+            const int* ev = visits.data() + (size_t)g * E;
+            int best = 0;
+            for (int i = 1; i < n; ++i) if (ev[best] < ev[i]) best = i;                // most_visited_action: first maximum (:29-39)
+            for (int i = 0; i < n; ++i) t->res.total_nodes += (uint64_t)std::max(0, ev[i]);
+            actA[g] = mA[(size_t)g * E + best]; actB[g] = mB[(size_t)g * E + best];
+            t->games[sl.gameIndex].actions.push_back("(" + uci_move(actA[g]) + "," + uci_move(actB[g]) + ")");   // action_uci :41-49
+            applyMask[g] = 1;
+            sl.macroPly++; sl.team ^= 1; sl.adv = !sl.adv;
+        }
+        if (int rc = hm_sp_apply(s->sp, actA.data(), actB.data(), applyMask.data())) return rc;
+        // slots whose game ended without a move restart at the top of the loop
+        {
+            std::fill(mask.begin(), mask.end(), 0);
+            bool r = false;
+            for (int g = 0; g < G; ++g) {
+                TSlot& sl = t->slots[g];
+                if (!sl.active && !applyMask[g]) { if (tournament_start(t, sl, init[g])) { mask[g] = 1; r = true; } }
+            }
+            if (r) if (int rc = hm_sp_set_games(s->sp, init.data(), mask.data())) return rc;
+        }
+    }
+    return 0;
+}
+
+// result bookkeeping in game order (tournament.cc:424-452)
+static void tournament_account(hm_tournament* t) {
+    hm_tournament_result& r = t->res;
+    t->pairScores.clear();
+    double currentPairPoints = 0.0;
+    for (size_t i = 0; i < t->games.size(); ++i) {
+        const TGame& g = t->games[i];
+        if (!g.done) break;
+        const size_t pairIndex = i / 2;
+        const int contenderTeam = i % 2 == 0 ? HM_WHITE : HM_BLACK;
+        const int startTeam = pairIndex % 2 == 0 ? HM_WHITE : HM_BLACK;
+        const bool contenderHasTimeAdvantage = contenderTeam != startTeam;
+        int outcome = 0;
+        if (g.winner < 0) r.draws++;
+        else if (g.winner == contenderTeam) { r.contender_wins++; outcome = 1; }
+        else { r.baseline_wins++; outcome = -1; }
+        auto record = [&](hm_tournament_breakdown& b) { if (outcome > 0) b.wins++; else if (outcome < 0) b.losses++; else b.draws++; };
+        record(contenderTeam == HM_WHITE ? r.as_white : r.as_black);
+        record(contenderHasTimeAdvantage ? r.up_time : r.down_time);
+        currentPairPoints += outcome > 0 ? 1.0 : outcome == 0 ? 0.5 : 0.0;
+        if (i % 2 == 1) { t->pairScores.push_back(currentPairPoints / 2.0); currentPairPoints = 0.0; }
+        if (g.termination == 0) r.checkmates++;
+        else if (g.termination == 1) r.no_legal_actions++;
+        else if (g.termination == 2) r.drawn_terminations++;
+        else r.macro_ply_limits++;
+    }
+    fill_statistics(r, t->pairScores);
+}
+
+static std::string tournament_summary_text(const hm_tournament* t, const std::string& contenderName, const std::string& baselineName) {   // write_summary :117-187
+    const hm_tournament_config& c = t->cfg;
+    const hm_tournament_result& r = t->res;
+    std::ostringstream o;
+    o << std::fixed << std::setprecision(6) << "{\n"
+      << "  \"contender\": \"" << contenderName << "\",\n" << "  \"baseline\": \"" << baselineName << "\",\n"
+      << "  \"games\": " << (r.contender_wins + r.baseline_wins + r.draws) << ",\n" << "  \"nodes_per_move\": " << c.nodes << ",\n"
+      << "  \"move_time_ms\": " << c.move_time_ms << ",\n" << "  \"contender_batch_size\": " << c.contender_batch_size << ",\n"
+      << "  \"baseline_batch_size\": " << c.baseline_batch_size << ",\n" << "  \"seed\": " << c.seed << ",\n"
+      << "  \"contender_pw_coefficient\": " << c.contender_pw_coefficient << ",\n"
+      << "  \"baseline_pw_coefficient\": " << c.baseline_pw_coefficient << ",\n"
+      << "  \"contender_wins\": " << r.contender_wins << ",\n" << "  \"baseline_wins\": " << r.baseline_wins << ",\n"
+      << "  \"draws\": " << r.draws << ",\n" << "  \"contender_score\": " << r.contender_score << ",\n" << "  \"contender_elo\": ";
+    if (r.has_elo) o << r.contender_elo; else o << "null";
+    o << ",\n  \"confidence_method\": \"" << (r.paired_method ? "paired-opening normal approximation" : "game-level Wilson approximation") << "\",\n"
+      << "  \"score_confidence_95\": ";
+    if (r.has_score_ci) o << '[' << r.score_ci[0] << ", " << r.score_ci[1] << ']'; else o << "null";
+    o << ",\n  \"elo_confidence_95\": ";
+    if (r.has_elo_ci) o << '[' << r.elo_ci[0] << ", " << r.elo_ci[1] << ']'; else o << "null";
+    o << ",\n  \"contender_breakdown\": {\n";
+    auto bd = [&](const char* name, const hm_tournament_breakdown& b, bool comma) {
+        o << "    \"" << name << "\": {\"wins\": " << b.wins << ", \"losses\": " << b.losses << ", \"draws\": " << b.draws << "}" << (comma ? "," : "") << '\n';
+    };
+    bd("white", r.as_white, true); bd("black", r.as_black, true); bd("up_time", r.up_time, true); bd("down_time", r.down_time, false);
+    o << "  },\n" << "  \"terminations\": {\n" << "    \"checkmate\": " << r.checkmates << ",\n"
+      << "    \"no_legal_action\": " << r.no_legal_actions << ",\n" << "    \"draw\": " << r.drawn_terminations << ",\n"
+      << "    \"macro_ply_limit\": " << r.macro_ply_limits << "\n" << "  }\n" << "}\n";
+    return o.str();
+}
+static std::string tournament_pgn_text(const hm_tournament* t, const std::string& contenderName, const std::string& baselineName) {   // append_game_pgn :89-115
+    std::ostringstream o;
+    for (size_t i = 0; i < t->games.size(); ++i) {
+        const TGame& g = t->games[i];
+        if (!g.done) break;
+        const int contenderTeam = i % 2 == 0 ? HM_WHITE : HM_BLACK;
+        const std::string result = g.winner == HM_WHITE ? "1-0" : g.winner == HM_BLACK ? "0-1" : "1/2-1/2";
+        o << "[Event \"Hivemind Network Tournament\"]\n" << "[Site \"Hivemind Engine\"]\n" << "[Round \"" << (i + 1) << "\"]\n"
+          << "[Variant \"bughouse\"]\n" << "[WhiteTeam \"" << (contenderTeam == HM_WHITE ? contenderName : baselineName) << "\"]\n"
+          << "[BlackTeam \"" << (contenderTeam == HM_BLACK ? contenderName : baselineName) << "\"]\n"
+          << "[Result \"" << result << "\"]\n" << "[Termination \"" << kTermination[g.termination] << "\"]\n\n";
+        for (size_t k = 0; k < g.actions.size(); ++k) o << (k + 1) << ". " << g.actions[k] << ' ';
+        o << result << "\n\n";
+    }
+    return o.str();
+}
+
+extern "C" {
+
+void hm_tournament_config_default(hm_tournament_config* c) {   // tools/tournament.h:15-27
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->games = 20; c->nodes = 400; c->move_time_ms = 0; c->contender_batch_size = 8; c->baseline_batch_size = 8;
+    c->max_macro_plies = 400; c->dirichlet_alpha = 0.3f; c->dirichlet_epsilon = 0.10f;
+    c->contender_pw_coefficient = 2.0f; c->baseline_pw_coefficient = 2.0f; c->seed = 1; c->concurrent_games = 64;
+}
+
+int hm_tournament_create(const hm_tournament_config* cfg, const hm_search_config* scfg, const hm_eval_io* io, const hm_net* baseline_net,
+                         hm_eval_fn fn, void* user, hm_tournament** out) {
+    if (!cfg || !io || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    const hm_tournament_config& c = *cfg;
+    // run_tournament's argument checks, same texts (tournament.cc:334-358)
+    if (c.games == 0 || c.games % 2 != 0) return hm_fail(HM_ERR_INVALID, "Tournament games must be a positive even number");
+    if ((c.nodes == 0) == (c.move_time_ms <= 0) || c.max_macro_plies == 0) return hm_fail(HM_ERR_INVALID, "Tournament requires exactly one positive nodes or movetime limit");
+    if (c.contender_batch_size <= 0 || c.baseline_batch_size <= 0) return hm_fail(HM_ERR_INVALID, "Tournament batch sizes must be positive");
+    if (c.dirichlet_alpha < 0.0f || c.dirichlet_epsilon < 0.0f || c.dirichlet_epsilon > 1.0f) return hm_fail(HM_ERR_INVALID, "Invalid tournament Dirichlet configuration");
+    if (!std::isfinite(c.contender_pw_coefficient) || !std::isfinite(c.baseline_pw_coefficient) || c.contender_pw_coefficient <= 0.0f || c.baseline_pw_coefficient <= 0.0f)
+        return hm_fail(HM_ERR_INVALID, "Tournament PW coefficients must be positive and finite");
+    // what this engine does not build
+    if (c.move_time_ms > 0) return hm_fail(HM_ERR_INVALID, "time-managed tournament search is not built: give a node budget");
+    if (c.contender_batch_size != 8 || c.baseline_batch_size != 8) return hm_fail(HM_ERR_INVALID, "only the default batch size 8 is built");
+    if (c.concurrent_games < 1) return hm_fail(HM_ERR_INVALID, "concurrent_games must be positive");
+    if ((io->net != nullptr) != (baseline_net != nullptr)) return hm_fail(HM_ERR_INVALID, "give both networks, or a callback that serves both");
+    hm_selfplay_config sc;
+    hm_selfplay_config_default(&sc);
+    sc.games = c.games; sc.nodes = c.nodes; sc.max_macro_plies = c.max_macro_plies; sc.node_random_factor = 0.0;
+    sc.seed = c.seed ? c.seed : 1; sc.concurrent_games = (int)std::min<uint64_t>((uint64_t)c.concurrent_games, c.games);
+    hm_search_config search;
+    if (scfg) search = *scfg; else hm_search_config_default(&search);
+    search.pw_coefficient = c.contender_pw_coefficient;                  // TournamentConfig::searchConfigFor (tournament.h:34-41):
+    search.root_pw_coefficient = c.contender_pw_coefficient;             // one coefficient for root and interior nodes
+    hm_tournament* t = new hm_tournament();
+    t->cfg = c;
+    t->cfg.concurrent_games = sc.concurrent_games;
+    if (int rc = hm_selfplay_create(&sc, &search, io, fn, user, &t->core)) { delete t; return rc; }
+    hm_selfplay* s = t->core;
+    if (baseline_net) {
+        s->net2 = baseline_net;
+        bool ok = hipMalloc(&s->d_netSel, (size_t)s->G) == hipSuccess;
+        for (int k = 0; k < 4 && ok; ++k) ok = hipMalloc(&s->d_rowsNet[k >> 1][k & 1], sizeof(int32_t) * s->G) == hipSuccess;
+        if (!ok) { hm_selfplay_destroy(s); delete t; return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed"); }
+        (void)hipMemset(s->d_netSel, 0, (size_t)s->G);
+    }
+    *out = t;
+    return 0;
+}
+
+int hm_tournament_run(hm_tournament* t, hm_tournament_result* out) {
+    if (!t) return hm_fail(HM_ERR_INVALID, "null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    t->res = hm_tournament_result{};
+    t->core->res = hm_selfplay_result{};
+    const int rc = tournament_run_impl(t);
+    const std::string msg = rc ? std::string(hm_last_error()) : std::string();
+    tournament_account(t);
+    t->res.search_iterations = t->core->res.search_iterations;
+    t->res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out) *out = t->res;
+    if (rc) return hm_fail(rc, msg);
+    return 0;
+}
+
+int hm_tournament_acting(const hm_tournament* t, uint8_t* acting) {
+    if (!t || !acting) return hm_fail(HM_ERR_INVALID, "null argument");
+    std::memcpy(acting, t->acting.data(), t->acting.size());
+    return 0;
+}
+uint64_t hm_tournament_pair_scores(const hm_tournament* t, const double** scores) {
+    if (!t) return 0;
+    if (scores) *scores = t->pairScores.data();
+    return t->pairScores.size();
+}
+static int64_t copy_text(const std::string& text, char* out, int64_t cap) {
+    if ((int64_t)text.size() + 1 > cap || !out) return -(int64_t)text.size() - 1;
+    std::memcpy(out, text.c_str(), text.size() + 1);
+    return (int64_t)text.size();
+}
+int64_t hm_tournament_summary(const hm_tournament* t, const char* contender_name, const char* baseline_name, char* out, int64_t cap) {
+    if (!t || !contender_name || !baseline_name) return 0;
+    return copy_text(tournament_summary_text(t, contender_name, baseline_name), out, cap);
+}
+int64_t hm_tournament_pgn(const hm_tournament* t, const char* contender_name, const char* baseline_name, char* out, int64_t cap) {
+    if (!t || !contender_name || !baseline_name) return 0;
+    return copy_text(tournament_pgn_text(t, contender_name, baseline_name), out, cap);
+}
+int hm_tournament_write_reports(const hm_tournament* t, const char* dir, const char* contender_name, const char* baseline_name) {
+    if (!t || !dir || !contender_name || !baseline_name) return hm_fail(HM_ERR_INVALID, "null argument");
+    std::error_code ec;
+    std::filesystem::create_directories(dir, ec);
+    if (ec) return hm_fail(HM_ERR_INVALID, std::string("Unable to create ") + dir);
+    const std::string base(dir);
+    {
+        std::ofstream f(base + "/games.pgn", std::ios::trunc);
+        if (!f) return hm_fail(HM_ERR_INVALID, "Unable to append tournament PGN: " + base + "/games.pgn");
+        f << tournament_pgn_text(t, contender_name, baseline_name);
+    }
+    const std::string path = base + "/summary.json", tmp = path + ".tmp";
+    {
+        std::ofstream f(tmp, std::ios::trunc);
+        if (!f) return hm_fail(HM_ERR_INVALID, "Unable to write tournament summary: " + path);
+        f << tournament_summary_text(t, contender_name, baseline_name);
+        f.close();
+        if (!f) return hm_fail(HM_ERR_INVALID, "Failed to finalize tournament summary: " + path);
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) return hm_fail(HM_ERR_INVALID, "Unable to publish " + path);
+    return 0;
+}
+int hm_tournament_destroy(hm_tournament* t) {
+    if (!t) return 0;
+    if (t->core) hm_selfplay_destroy(t->core);
+    delete t;
+    return 0;
+}
+int hm_tournament_statistics(uint64_t contender_wins, uint64_t baseline_wins, uint64_t draws, const double* pair_scores, uint64_t pairs,
+                             hm_tournament_result* out) {
+    if (!out || (pairs && !pair_scores)) return hm_fail(HM_ERR_INVALID, "null argument");
+    *out = hm_tournament_result{};
+    out->contender_wins = contender_wins; out->baseline_wins = baseline_wins; out->draws = draws;
+    fill_statistics(*out, std::vector<double>(pair_scores, pair_scores + pairs));
+    return 0;
+}
+int hm_move_uci(hm_move move, char* out, int cap) {
+    if (!out || cap <= 0) return hm_fail(HM_ERR_INVALID, "null argument");
+    const std::string text = uci_move(move);
+    std::snprintf(out, (size_t)cap, "%s", text.c_str());
+    return (int)text.size();
 }
 
 }  // extern "C"

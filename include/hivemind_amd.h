@@ -185,6 +185,9 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
  * (Board::positionHistory grows by one key per push, board.h:95-102); 0 = the default of 1024 keys. */
 int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_search_config* cfg, hm_sp** out);
 int hm_sp_destroy(hm_sp* sp);
+/* Progressive-widening schedule per game slot (TournamentConfig::searchConfigFor, tools/tournament.h:34-41): profiles[g] != 0
+ * makes slot g search with the alternate coefficients (root and interior); 0 = the engine's hm_search_config. */
+int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw_coefficient, const uint8_t* profiles);
 /* (Re)start games from host boards[n_games] (Board::set, board.cc:27-49: history restarts);
  * team / time_adv of each hm_board give the side to act.  mask[g]==0 leaves game g alone. */
 int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask);
@@ -383,6 +386,64 @@ int hm_selfplay_destroy(hm_selfplay* sp);
 /* ChunkWriter::flush (selfplay.cc:105-151): header 'HVM4' u32 4, u16 74, u16 4672, u64 count + samples,
  * published atomically via .tmp + rename. */
 int hm_hvm4_write_chunk(const char* path, const uint8_t* records, uint64_t nbytes, uint64_t count);
+
+/* ================================================================== */
+/* paired network tournament: run_tournament (tools/tournament.h:15-75, */
+/* tools/tournament.cc:328-465) for `concurrent_games` slots on one GPU. */
+/* Game i: pair i/2, the contender plays White in even games, the pair's  */
+/* starting team alternates, every macro-ply is searched with `nodes`     */
+/* nodes by the network of the team to move (its own PW coefficient for    */
+/* root and interior nodes), root noise seeded by (seed, pair, macro-ply), */
+/* and the most visited joint action is played.  Games are independent     */
+/* (no shared RNG), so they run in lockstep slots; results, summary.json   */
+/* and games.pgn are produced in game order and are byte-identical to the  */
+/* sequential loop under the same evaluators.                              */
+/* Not built: move_time_ms > 0 (time-managed search) and batch sizes other */
+/* than 8 -> HM_ERR_INVALID at create.                                     */
+/* ================================================================== */
+typedef struct hm_tournament hm_tournament;
+typedef struct hm_tournament_config {     /* TournamentConfig, tools/tournament.h:15-42 */
+    uint64_t games, nodes;
+    int32_t  move_time_ms, contender_batch_size, baseline_batch_size;
+    uint64_t max_macro_plies;
+    float    dirichlet_alpha, dirichlet_epsilon;
+    float    contender_pw_coefficient, baseline_pw_coefficient;
+    uint64_t seed;
+    int32_t  concurrent_games;            /* game slots searched in lockstep on this GPU */
+} hm_tournament_config;
+void hm_tournament_config_default(hm_tournament_config* cfg);
+typedef struct hm_tournament_breakdown { uint64_t wins, losses, draws; } hm_tournament_breakdown;
+typedef struct hm_tournament_result {     /* TournamentResult, tools/tournament.h:50-73 + its statistics (tournament.cc:247-326) */
+    uint64_t contender_wins, baseline_wins, draws;
+    hm_tournament_breakdown as_white, as_black, up_time, down_time;
+    uint64_t checkmates, no_legal_actions, drawn_terminations, macro_ply_limits;
+    uint64_t pairs;                       /* pair scores recorded (hm_tournament_pair_scores) */
+    double   contender_score;
+    int32_t  has_elo, has_score_ci, has_elo_ci, paired_method;   /* paired_method: 1 = "paired-opening normal approximation" */
+    double   contender_elo, score_ci[2], elo_ci[2];
+    uint64_t searched_positions, total_nodes, search_iterations;
+    double   seconds;
+} hm_tournament_result;
+/* io->net = the contender's network; baseline_net = the baseline's (both NULL: callback evaluator, which must serve both
+ * networks: hm_tournament_acting tells it which slots the contender is searching). */
+int hm_tournament_create(const hm_tournament_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io, const hm_net* baseline_net,
+                         hm_eval_fn fn, void* user, hm_tournament** out);
+int hm_tournament_run(hm_tournament* t, hm_tournament_result* out);
+/* acting[concurrent_games]: 1 where the contender's network evaluates the slot's current search, 0 baseline (valid inside the callback). */
+int hm_tournament_acting(const hm_tournament* t, uint8_t* acting);
+uint64_t hm_tournament_pair_scores(const hm_tournament* t, const double** scores);
+/* summary.json (write_summary :117-187) / games.pgn (append_game_pgn :89-115) of the finished run as text; returns the
+ * length, or -(needed size) when cap is too small. */
+int64_t hm_tournament_summary(const hm_tournament* t, const char* contender_name, const char* baseline_name, char* out, int64_t cap);
+int64_t hm_tournament_pgn(const hm_tournament* t, const char* contender_name, const char* baseline_name, char* out, int64_t cap);
+/* <dir>/summary.json (atomically via .tmp + rename) and <dir>/games.pgn, the reference's report files. */
+int hm_tournament_write_reports(const hm_tournament* t, const char* dir, const char* contender_name, const char* baseline_name);
+int hm_tournament_destroy(hm_tournament* t);
+/* The statistics alone (host-only): score, Elo and the 95 % intervals of a W-L-D record with optional pair scores. */
+int hm_tournament_statistics(uint64_t contender_wins, uint64_t baseline_wins, uint64_t draws, const double* pair_scores, uint64_t pairs,
+                             hm_tournament_result* out);
+/* UCI::move text of a move of this variant (Board::uci_move, environment/board.h:340-350; MOVE_NONE -> "pass"). */
+int hm_move_uci(hm_move move, char* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -248,4 +248,7 @@ double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, i
 #if __has_include("selfplay.hpp")
 #include "oracle_selfplay.cc"
 #endif
+#if __has_include("tournament.hpp")
+#include "oracle_tournament.cc"
+#endif
 #endif

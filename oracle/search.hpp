@@ -355,11 +355,12 @@ typedef std::function<void(const uint16_t* planes, int n, EvalOutputs& out)> Eva
 
 // Deterministic stand-in network for parity tests: FNV-1a over the 4736 fp16
 // input words -> splitmix64 stream -> heads quantised to 1e-3 and rounded to fp16.
-inline void hash_evaluator(const uint16_t* planes, int n, EvalOutputs& out) {
+// salt != 0 gives a second, unrelated deterministic "network" (tournaments need two)
+inline void hash_evaluator_salted(const uint16_t* planes, int n, uint64_t salt, EvalOutputs& out) {
     out.value.assign(n, 0); out.piA.assign((size_t)n * HM_POLICY_VALUES, 0); out.piB.assign((size_t)n * HM_POLICY_VALUES, 0);
     out.wdl.assign((size_t)n * 3, 0); out.movesLeft.assign(n, 0);
     for (int i = 0; i < n; ++i) {
-        uint64_t h = 0xcbf29ce484222325ULL;
+        uint64_t h = 0xcbf29ce484222325ULL ^ salt;
         const uint16_t* p = planes + (size_t)i * HM_PLANE_VALUES;
         for (int k = 0; k < HM_PLANE_VALUES; ++k) { h ^= p[k]; h *= 0x100000001b3ULL; }
         uint64_t s = h;
@@ -383,6 +384,8 @@ inline void hash_evaluator(const uint16_t* planes, int n, EvalOutputs& out) {
         }
     }
 }
+
+inline void hash_evaluator(const uint16_t* planes, int n, EvalOutputs& out) { hash_evaluator_salted(planes, n, 0, out); }
 
 // ---- common/utils.h:127-167,226-243 -------------------------------------------------------
 inline std::vector<float> normalize_logits(const std::vector<float>& logits, int exp_mode) {

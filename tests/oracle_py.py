@@ -305,3 +305,88 @@ class SelfPlayOracle:
         k = lib.ora_selfplay_last_actions(a.ctypes.data, b.ctypes.data, r.ctypes.data, 2048)
         return (buf[:n].tobytes(), dict(samples=int(info[0]), raw_plies=int(info[1]), winner=int(info[2]), termination=int(info[3]), nodes=int(info[4])),
                 list(zip(a[:k].tolist(), b[:k].tolist(), r[:k].tolist())))
+
+
+# ---- tournament oracle (oracle/tournament.hpp) -----------------------------------------------------
+class TournamentCfg(C.Structure):
+    """Layout of hm_tournament_config (include/hivemind_amd.h) = TournamentConfig (tools/tournament.h:15-42) + slot count."""
+    _fields_ = [("games", C.c_uint64), ("nodes", C.c_uint64), ("move_time_ms", C.c_int32), ("contender_batch_size", C.c_int32),
+                ("baseline_batch_size", C.c_int32), ("max_macro_plies", C.c_uint64), ("dirichlet_alpha", C.c_float),
+                ("dirichlet_epsilon", C.c_float), ("contender_pw_coefficient", C.c_float), ("baseline_pw_coefficient", C.c_float),
+                ("seed", C.c_uint64), ("concurrent_games", C.c_int32)]
+
+
+def tournament_cfg(**kw):
+    """Reference defaults (tools/tournament.h:15-27) with overrides."""
+    c = TournamentCfg(games=20, nodes=400, move_time_ms=0, contender_batch_size=8, baseline_batch_size=8, max_macro_plies=400,
+                      dirichlet_alpha=0.3, dirichlet_epsilon=0.10, contender_pw_coefficient=2.0, baseline_pw_coefficient=2.0,
+                      seed=1, concurrent_games=64)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+lib.ora_tournament_new.restype, lib.ora_tournament_new.argtypes = _vp, [_vp, _i, _i, _u64, _u64]
+lib.ora_tournament_free.restype, lib.ora_tournament_free.argtypes = None, [_vp]
+lib.ora_tournament_run.restype, lib.ora_tournament_run.argtypes = _i, [_vp, _vp, _i]
+lib.ora_tournament_summary.restype, lib.ora_tournament_summary.argtypes = C.c_int64, [_vp, C.c_char_p, C.c_char_p, _vp, C.c_int64]
+lib.ora_tournament_pgn.restype, lib.ora_tournament_pgn.argtypes = C.c_int64, [_vp, C.c_char_p, C.c_char_p, _vp, C.c_int64]
+lib.ora_tournament_stats.restype, lib.ora_tournament_stats.argtypes = None, [_u64, _u64, _u64, _vp, _i, _vp]
+lib.ora_move_uci.restype, lib.ora_move_uci.argtypes = _i, [C.c_uint32, _vp, _i]
+lib.ora_hash_evaluator_salted.restype, lib.ora_hash_evaluator_salted.argtypes = None, [_vp, _i, _u64, _vp, _vp, _vp, _vp, _vp]
+
+
+def hash_evaluator_salted(planes_u16, salt):
+    """The deterministic stand-in network with a salt: (value, piA, piB, wdl, ml) as uint16 fp16 bit patterns."""
+    p = np.ascontiguousarray(planes_u16, dtype=np.uint16).reshape(-1, 4736)
+    n = len(p)
+    v = np.zeros(n, np.uint16); a = np.zeros((n, 4672), np.uint16); b = np.zeros((n, 4672), np.uint16)
+    w = np.zeros((n, 3), np.uint16); m = np.zeros(n, np.uint16)
+    lib.ora_hash_evaluator_salted(p.ctypes.data, n, salt, v.ctypes.data, a.ctypes.data, b.ctypes.data, w.ctypes.data, m.ctypes.data)
+    return v, a, b, w, m
+
+
+def move_uci(m):
+    buf = C.create_string_buffer(16)
+    lib.ora_move_uci(int(m), buf, 16)
+    return buf.value.decode()
+
+
+def tournament_stats(contender_wins, baseline_wins, draws, pairs=()):
+    p = np.ascontiguousarray(pairs, dtype=np.float64)
+    out = np.zeros(10, np.float64)
+    lib.ora_tournament_stats(contender_wins, baseline_wins, draws, p.ctypes.data, len(p), out.ctypes.data)
+    return dict(score=out[0], elo=out[2] if out[1] else None, score_ci=(out[4], out[5]) if out[3] else None,
+                elo_ci=(out[7], out[8]) if out[6] else None,
+                method="paired-opening normal approximation" if out[9] else "game-level Wilson approximation")
+
+
+class TournamentOracle:
+    """Sequential restatement of run_tournament with two salted hash evaluators."""
+
+    def __init__(self, cfg, salt_contender=0, salt_baseline=0x5EED, tie_mode=1, exp_mode=1):
+        self.h = lib.ora_tournament_new(C.byref(cfg), tie_mode, exp_mode, salt_contender, salt_baseline)
+
+    def __del__(self):
+        try:
+            lib.ora_tournament_free(self.h)
+        except Exception:
+            pass
+
+    def run(self):
+        err = C.create_string_buffer(256)
+        if lib.ora_tournament_run(self.h, err, 256) != 0:
+            raise ValueError(err.value.decode())
+
+    def _text(self, fn, a, b):
+        cap = 1 << 22
+        buf = C.create_string_buffer(cap)
+        n = fn(self.h, a.encode(), b.encode(), buf, cap)
+        assert n >= 0
+        return buf.value.decode()
+
+    def summary(self, a="contender", b="baseline"):
+        return self._text(lib.ora_tournament_summary, a, b)
+
+    def pgn(self, a="contender", b="baseline"):
+        return self._text(lib.ora_tournament_pgn, a, b)
