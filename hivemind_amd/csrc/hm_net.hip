@@ -566,7 +566,7 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
     }
 }
 
-template <int CTILES, bool K5>      // CTILES = C / 32 (2 or 4); cin_pad must be 80
+template <int CTILES, bool K5>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
 __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
                                                               const h16* __restrict__ planes, int n, int copMax, int uHalfs,
                                                               h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
@@ -577,20 +577,23 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const NetDesc& nd = *ndp;
-    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES;       // C = 64 or 128: 2 or 4 column tiles x 2 square tiles
+    // C = 64, 128 or 384: an N = C GEMM is CTILES column tiles x 2 square tiles = 2*CTILES tiles of 32x32 over 8 waves, i.e.
+    // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
+    // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
+    // per chunk of copMax channels and carries the projection accumulators across the chunks in registers.
+    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8;
     h16* Xs = reinterpret_cast<h16*>(smem);                             // [65][ldx]
     h16* U = Xs + 65 * ldx;                                             // union region
     h16* Ss = U;                                                        // [65][ldx] (input staging uses pitch ldi)
-    h16* Y1 = U;                                                        // [cop][66]
-    h16* Y2 = U + (size_t)copMax * 66;                                  // [64][cop + 8]
-    float* Pf = reinterpret_cast<float*>(U + uHalfs);                   // per-block parameters: b1[cop], b2[cop], b3[C]  (uHalfs % 8 == 0)
-    h16* Pdw = reinterpret_cast<h16*>(Pf + 2 * copMax + C);             // depthwise weights [cop][k*k]
+    h16* Y1 = U;                                                        // [chunk][66]
+    h16* Y2 = U + (size_t)copMax * 66;                                  // [64][chunk + 8]
+    float* Pf = reinterpret_cast<float*>(U + uHalfs);                   // per-chunk parameters: b1[chunk], b2[chunk], b3[C]  (uHalfs % 8 == 0)
+    h16* Pdw = reinterpret_cast<h16*>(Pf + 2 * copMax + C);             // depthwise weights [chunk][k*k]
     float* Ev = reinterpret_cast<float*>(Pdw + (((size_t)copMax * 25 + 7) & ~(size_t)7));   // ECA / head scratch: [4][C] + [C] + 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = 8 * (lane >> 5);
-    const int stile = wave & 1, ctile = wave >> 1;                      // this wave's tile of an N = C GEMM (ctile < ctiles)
+    const int stile = wave & 1;                                         // the square half of every tile this wave computes
     const int sqL = stile * 32 + (lane & 31);                           // the square this lane feeds as an A-row / B-column
-    const bool ownsTile = ctile < ctiles;
 
     for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
         if (groupRows && (sIdx % group) >= groupRows[sIdx / group]) continue;
@@ -605,37 +608,40 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
         __syncthreads();
         HM_STAMP();   // input staged
         // ---- stem: 3x3 conv cin -> C (+bias, ReLU)
-        if (ownsTile) {
-            floatx16 acc = gemm_conv3<5, false>(zero16(), Ss, sqL, ldi, 64, kh, wh + nd.stem_w, ctiles, ctile, lane);
-            const int co = ctile * 32 + (lane & 31);
-            const float bias = wf[nd.stem_b + co];
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) Xs[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+        for (int i = 0; i < TPW; ++i) {
+            const int ctile = (wave + 8 * i) >> 1;
+            if (ctile < ctiles) {
+                floatx16 acc = gemm_conv3<5, false>(zero16(), Ss, sqL, ldi, 64, kh, wh + nd.stem_w, ctiles, ctile, lane);
+                const int co = ctile * 32 + (lane & 31);
+                const float bias = wf[nd.stem_b + co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) Xs[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+            }
         }
         __syncthreads();
         HM_STAMP();
-        // ---- mobile bottleneck blocks: three phases each over all `cop` expanded channels
+        // ---- mobile bottleneck blocks: three phases each over (a chunk of) the `cop` expanded channels
         for (int bi = 0; bi < nd.nblocks; ++bi) {
             const BlockDesc bd = nd.blk[bi];
-            const int cop = bd.cop, kk = bd.k, ld2 = cop + 8;
-            // parameter stage (consumed from the expand epilogue on): issued first so it overlaps the ECA phase
-            float* sb1 = Pf; float* sb2 = Pf + cop; float* sb3 = Pf + 2 * cop;
-            for (int i = tid; i < cop; i += 512) { sb1[i] = wf[bd.b1 + i]; sb2[i] = wf[bd.b2 + i]; }
+            const int cop = bd.cop, kk = bd.k;
+            float* sb1 = Pf; float* sb2 = Pf + copMax; float* sb3 = Pf + 2 * copMax;
             for (int i = tid; i < C; i += 512) sb3[i] = wf[bd.b3 + i];
-            for (int i = tid; i < cop * kk * kk; i += 512) Pdw[i] = wh[bd.dw + i];
             if (bd.eca) {   // x = x * hardsigmoid(W_eca . mean_sq(x) + b)   (builder_util.py:49-80, centre tap)
                 float* part = Ev;            // [4][C] partial sums, then partial dot products
                 float* Mv = Ev + 4 * C;      // [C] channel means
-                const int c = tid % C, p = tid / C;                    // 512 / C partitions (4 at C=128, 8 at C=64: use 4)
-                if (p < 4) {
+                // work item = (quarter p of the squares / input channels, channel c): 4*C items over 512 threads
+                for (int it = tid; it < 4 * C; it += 512) {
+                    const int c = it % C, p = it / C;
                     float sacc = 0.0f;
                     for (int sq = 16 * p; sq < 16 * p + 16; ++sq) sacc += (float)Xs[sq * ldx + c];
                     part[p * C + c] = sacc;
                 }
                 __syncthreads();
-                if (tid < C) Mv[tid] = (part[tid] + part[C + tid] + part[2 * C + tid] + part[3 * C + tid]) * (1.0f / 64.0f);
+                for (int c = tid; c < C; c += 512) Mv[c] = (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]) * (1.0f / 64.0f);
                 __syncthreads();
-                if (p < 4) {
+                for (int it = tid; it < 4 * C; it += 512) {
+                    const int c = it % C, p = it / C;
                     const h16* we = wh + bd.ecaw;                       // [ci][co]
                     const int q4 = C >> 2;
                     float sacc = 0.0f;
@@ -649,9 +655,9 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                     part[p * C + c] = sacc;
                 }
                 __syncthreads();
-                if (tid < C) {
-                    const float sg = part[tid] + part[C + tid] + part[2 * C + tid] + part[3 * C + tid] + wf[bd.ecab + tid];
-                    Mv[tid] = fminf(fmaxf(sg * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+                for (int c = tid; c < C; c += 512) {
+                    const float sg = part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c] + wf[bd.ecab + c];
+                    Mv[c] = fminf(fmaxf(sg * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
                 }
                 __syncthreads();
                 for (int i = tid; i < 64 * C; i += 512) {
@@ -659,42 +665,63 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                     Xs[sq * ldx + cc] = (h16)((float)Xs[sq * ldx + cc] * Mv[cc]);
                 }
             }
-            __syncthreads();
-            HM_STAMP();   // parameters staged (+ ECA)
-            // phase 1 — 1x1 expand, transposed: Y1[ch][sq] = relu(W1^T x^T + b1); tiles = (cop/32) x 2 over 8 waves
-            {
-                const int copTiles = cop >> 5, tiles = copTiles * 2;
-                const h16* brow = Xs + sqL * ldx + kh;                  // tile's square half = t & 1 == stile when t = wave + 8i
-                for (int t = wave; t < tiles; t += 8) {
-                    const int ct = t >> 1;                              // (t & 1) == (wave & 1) == stile
-                    const floatx16 e = gemm_tile<true>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct, lane);
+            floatx16 pacc[TPW];                                         // projection accumulators, carried over the chunks
 #pragma unroll
-                    for (int rg = 0; rg < 16; ++rg) {
-                        const int ch = ct * 32 + drow(rg, lane);
-                        Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+            for (int i = 0; i < TPW; ++i) pacc[i] = zero16();
+            for (int ch0 = 0; ch0 < cop; ch0 += copMax) {
+                const int chunk = min(copMax, cop - ch0), ld2 = chunk + 8;
+                // parameter stage of this chunk (the previous chunk's phase 3 no longer reads Pf / Pdw: barrier at its end)
+                for (int i = tid; i < chunk; i += 512) { sb1[i] = wf[bd.b1 + ch0 + i]; sb2[i] = wf[bd.b2 + ch0 + i]; }
+                for (int i = tid; i < chunk * kk * kk; i += 512) Pdw[i] = wh[bd.dw + (size_t)ch0 * kk * kk + i];
+                __syncthreads();
+                HM_STAMP();   // parameters staged (+ ECA)
+                // phase 1 — 1x1 expand, transposed: Y1[ch][sq] = relu(W1^T x^T + b1); tiles = (chunk/32) x 2 over 8 waves
+                {
+                    const int copTiles = cop >> 5, tiles = (chunk >> 5) * 2, ct0 = ch0 >> 5;
+                    const h16* brow = Xs + sqL * ldx + kh;              // tile's square half = t & 1 == stile when t = wave + 8i
+                    for (int t = wave; t < tiles; t += 8) {
+                        const int ct = t >> 1;                          // (t & 1) == (wave & 1) == stile
+                        const floatx16 e = gemm_tile<true>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+#pragma unroll
+                        for (int rg = 0; rg < 16; ++rg) {
+                            const int ch = ct * 32 + drow(rg, lane);
+                            Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+                        }
                     }
                 }
-            }
-            __syncthreads();
-            HM_STAMP();   // expand done
-            // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows)
-            for (int item = tid; item < cop * 4; item += 512) {
-                const int ch = item % cop, g = item / cop;
-                const h16* wd = Pdw + (size_t)ch * kk * kk;
-                if (!K5 || kk == 3) depthwise_rows_ld<3>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
-                else depthwise_rows_ld<5>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
-            }
-            __syncthreads();
-            HM_STAMP();   // depthwise done
-            // phase 3 — 1x1 project + bias + residual: one 32x32 tile per wave, K = cop
-            if (ownsTile) {
-                const floatx16 acc = gemm_tile<false>(zero16(), Y2 + sqL * ld2 + kh, cop >> 4, wh + bd.w2, ctiles, ctile, lane);
-                const int co = ctile * 32 + (lane & 31);
-                const float bias = sb3[co];
+                __syncthreads();
+                HM_STAMP();   // expand done
+                // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows)
+                for (int item = tid; item < chunk * 4; item += 512) {
+                    const int ch = item % chunk, g = item / chunk;
+                    const h16* wd = Pdw + (size_t)ch * kk * kk;
+                    if (!K5 || kk == 3) depthwise_rows_ld<3>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
+                    else depthwise_rows_ld<5>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
+                }
+                __syncthreads();
+                HM_STAMP();   // depthwise done
+                // phase 3 — 1x1 project, K = this chunk's channels: k-steps ch0/16 .. of W2
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int sq = stile * 32 + drow(rg, lane);
-                    Xs[sq * ldx + co] = (h16)((float)Xs[sq * ldx + co] + acc[rg] + bias);
+                for (int i = 0; i < TPW; ++i) {
+                    const int ctile = (wave + 8 * i) >> 1;
+                    if (ctile < ctiles)
+                        pacc[i] = gemm_tile<false>(pacc[i], Y2 + sqL * ld2 + kh, chunk >> 4, wh + bd.w2 + (size_t)(ch0 >> 4) * ctiles * 512, ctiles, ctile, lane);
+                }
+                // (no barrier here: the next chunk's parameter stage and expand phase touch Pf / Pdw / Y1, which this phase does
+                // not read, and its depthwise phase — the next writer of Y2 — starts behind the barrier after its expand phase)
+            }
+            // + bias + residual
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int ctile = (wave + 8 * i) >> 1;
+                if (ctile < ctiles) {
+                    const int co = ctile * 32 + (lane & 31);
+                    const float bias = sb3[co];
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int sq = stile * 32 + drow(rg, lane);
+                        Xs[sq * ldx + co] = (h16)((float)Xs[sq * ldx + co] + pacc[i][rg] + bias);
+                    }
                 }
             }
             __syncthreads();
@@ -745,12 +772,16 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
         HM_STAMP();
         // ---- policy heads: shared 3x3 conv C -> C (+bias, ReLU) into Ss, then 3x3 C -> 146 (two boards)
         for (int i = tid; i < ldx; i += 512) Ss[64 * ldx + i] = (h16)0.0f;
-        if (ownsTile) {
-            const floatx16 acc = gemm_conv3<CTILES * 2, false>(zero16(), Xs, sqL, ldx, 64, kh, wh + nd.ps_w, ctiles, ctile, lane);
-            const int co = ctile * 32 + (lane & 31);
-            const float bias = wf[nd.ps_b + co];
 #pragma unroll
-            for (int rg = 0; rg < 16; ++rg) Ss[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+        for (int i = 0; i < TPW; ++i) {
+            const int ctile = (wave + 8 * i) >> 1;
+            if (ctile < ctiles) {
+                const floatx16 acc = gemm_conv3<CTILES * 2, false>(zero16(), Xs, sqL, ldx, 64, kh, wh + nd.ps_w, ctiles, ctile, lane);
+                const int co = ctile * 32 + (lane & 31);
+                const float bias = wf[nd.ps_b + co];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) Ss[(stile * 32 + drow(rg, lane)) * ldx + co] = (h16)fmaxf(acc[rg] + bias, 0.0f);
+            }
         }
         __syncthreads();
         HM_STAMP();
@@ -816,6 +847,7 @@ template <typename F>
 static hipError_t with_narrow(const hm_net* net, F f) {
     using namespace hmn;
     if (net->nd.C == 64) return net->k5 ? f(rise_forward_narrow<2, true>) : f(rise_forward_narrow<2, false>);
+    if (net->nd.C == 384) return net->k5 ? f(rise_forward_narrow<12, true>) : f(rise_forward_narrow<12, false>);
     return net->k5 ? f(rise_forward_narrow<4, true>) : f(rise_forward_narrow<4, false>);
 }
 template <typename F>
@@ -866,16 +898,23 @@ int hm_net_create(const int32_t* desc, size_t desc_ints, const void* d_wh, const
     hipError_t e = hipMemcpy(net->d_nd, &net->nd, sizeof(NetDesc), hipMemcpyHostToDevice);
     for (int wide = 0; wide < 2 && e == hipSuccess; ++wide)
         e = with_kernel(net, wide != 0, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    if (e == hipSuccess && nd.C <= 128 && nd.cin_pad == 80 && !std::getenv("HM_NET_NO_NARROW")) {
+    if (e == hipSuccess && (nd.C == 64 || nd.C == 128 || nd.C == 384) && nd.cin_pad == 80 && !std::getenv("HM_NET_NO_NARROW")) {
+        // the 8-wave kernel keeps `copMax` expanded channels of a block in LDS at a time; blocks wider than that (the deployed
+        // 384-channel net: up to 1152) are walked in chunks of copMax
         int copMax = 32;
         for (int i = 0; i < nd.nblocks; ++i) copMax = std::max(copMax, nd.blk[i].cop);
         const size_t ldxN = nd.C + 8, ldi = nd.cin_pad + 8;
-        size_t u = std::max((size_t)copMax * 66 + (size_t)64 * (copMax + 8), (size_t)65 * std::max(ldxN, ldi));
-        u = (u + 7) & ~(size_t)7;
-        const size_t bytes = (65 * ldxN + u) * 2 + (2 * (size_t)copMax + nd.C) * 4 + ((((size_t)copMax * 25 + 7) & ~(size_t)7) * 2) + (5 * (size_t)nd.C + 64) * 4;
-        if (bytes <= 160 * 1024) {
-            net->narrow = true; net->copMax = copMax; net->uHalfs = (int)u; net->ldsNarrow = bytes;
-            e = with_narrow(net, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); });
+        auto bytes_for = [&](int cm) {
+            size_t u = std::max((size_t)cm * 66 + (size_t)64 * (cm + 8), (size_t)65 * std::max(ldxN, ldi));
+            u = (u + 7) & ~(size_t)7;
+            return std::make_pair(u, (65 * ldxN + u) * 2 + (2 * (size_t)cm + nd.C) * 4 + ((((size_t)cm * 25 + 7) & ~(size_t)7) * 2) + (5 * (size_t)nd.C + 64) * 4);
+        };
+        if (const char* ce = std::getenv("HM_NET_COP_CHUNK")) copMax = std::max(64, std::atoi(ce) & ~63);
+        while (copMax > 64 && bytes_for(copMax).second > 160 * 1024) copMax -= 64;      // chunk size: a multiple of 64 channels that fits
+        const auto ub = bytes_for(copMax);
+        if (ub.second <= 160 * 1024) {
+            net->narrow = true; net->copMax = copMax; net->uHalfs = (int)ub.first; net->ldsNarrow = ub.second;
+            e = with_narrow(net, [&](auto kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ub.second); });
         }
     }
     if (e != hipSuccess) { (void)hipFree(net->d_nd); delete net; return hm_fail(HM_ERR_NO_DEVICE, std::string("hm_net_create: ") + hipGetErrorString(e)); }
