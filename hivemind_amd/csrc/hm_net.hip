@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256, OCC) void rise_forward_kernel(const NetDesc* _
 // that opens the phase.  im2col row offsets are computed once per convolution, not per k-step.
 // LDS: Xs[65][C+8] | union{ Ss[65][C+8] , Y1[cop][66] + Y2[64][cop+8] } | per-block parameter stage | ECA scratch.
 // =============================================================================================================
-constexpr int NPF = 8;                     // weight fragments in flight per wave
+// weight fragments in flight per wave: 8 for the narrow trunks (no spills, one tile per wave), 16 for the 384-channel net
+// (three tiles per wave, 24-step expansions: measured 0.90 -> 0.79 ms per position together with the dword depthwise reads)
 
 // LDS element offset of the source row of 3x3 tap t for square sq (or of the zero row for off-board taps)
 __device__ __forceinline__ int im2col_row(int sq, int t, int pitch, int zeroRow) {
@@ -473,33 +474,34 @@ __device__ __forceinline__ int im2col_row(int sq, int t, int pitch, int zeroRow)
 // drain the queue with vmcnt(0) at every step.  So: no branches around loads (the tail re-requests the last fragment
 // instead — an L1 hit), straight-line bodies.
 typedef int frag4 __attribute__((ext_vector_type(4)));
+typedef h16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half8 h8(frag4 x) { return __builtin_bit_cast(half8, x); }
 __device__ __forceinline__ frag4 lds_frag(const h16* p) { return *reinterpret_cast<const frag4*>(p); }
 
 // One 32x32 output tile, K = ksteps*16: operand X from LDS (`xrow` = this lane's row + 8*(lane>>5) halfs, k-step i at
 // xrow + i*16), operand W = packed fragments from global memory (k-step i of `tile` at wp + i*ws) with NPF requests in
 // flight.  WA = true: the weight fragment is the MFMA's A operand (transposed product D[ch][sq]), else its B operand.
-template <bool WA>
+template <bool WA, int Q>
 __device__ __forceinline__ floatx16 gemm_tile(floatx16 acc, const h16* xrow, int ksteps, const h16* w, int ntiles, int tile, int lane) {
     const frag4* wp = reinterpret_cast<const frag4*>(w) + (size_t)tile * 64 + lane;
     const size_t ws = (size_t)ntiles * 64;
     const int last = ksteps - 1;
-    frag4 q[NPF];
+    frag4 q[Q];
 #pragma unroll
-    for (int j = 0; j < NPF; ++j) q[j] = wp[(size_t)(j < last ? j : last) * ws];
+    for (int j = 0; j < Q; ++j) q[j] = wp[(size_t)(j < last ? j : last) * ws];
     int base = 0;
-    for (; base + NPF < ksteps; base += NPF) {                         // full groups: refill each slot right after its use
+    for (; base + Q < ksteps; base += Q) {                             // full groups: refill each slot right after its use
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
+        for (int j = 0; j < Q; ++j) {
             const frag4 x = lds_frag(xrow + (base + j) * 16);
             const frag4 f = q[j];
-            const int nxt = base + NPF + j;
+            const int nxt = base + Q + j;
             q[j] = wp[(size_t)(nxt < last ? nxt : last) * ws];
             acc = WA ? mfma(h8(f), h8(x), acc) : mfma(h8(x), h8(f), acc);
         }
     }
 #pragma unroll
-    for (int j = 0; j < NPF; ++j) {                                     // last (possibly partial) group: nothing left to request
+    for (int j = 0; j < Q; ++j) {                                       // last (possibly partial) group: nothing left to request
         if (base + j < ksteps) {
             const frag4 x = lds_frag(xrow + (base + j) * 16);
             acc = WA ? mfma(h8(q[j]), h8(x), acc) : mfma(h8(x), h8(q[j]), acc);
@@ -546,9 +548,17 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
     for (int r = 0; r < K + 1; ++r) {
         const int y = 2 * g - H + r;
 #pragma unroll
-        for (int x = 0; x < 8 + 2 * H; ++x) {
-            const int xx = x - H;
-            in[r][x] = (y >= 0 && y < 8 && xx >= 0 && xx < 8) ? (float)y1[y * 8 + xx] : 0.0f;
+        for (int x = 0; x < 8 + 2 * H; ++x) in[r][x] = 0.0f;
+        if (y >= 0 && y < 8) {
+            // one board row = 8 halfs = four dwords (the channel pitch of 66 halfs keeps rows 4-byte aligned): four LDS
+            // reads instead of eight 16-bit ones
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(y1 + y * 8);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const half2v v = __builtin_bit_cast(half2v, row[d]);
+                in[r][H + 2 * d] = (float)v[0];
+                in[r][H + 2 * d + 1] = (float)v[1];
+            }
         }
     }
 #pragma unroll
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
     // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
     // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
     // per chunk of copMax channels and carries the projection accumulators across the chunks in registers.
-    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8;
+    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8, NPF = CTILES > 4 ? 16 : 8;
     h16* Xs = reinterpret_cast<h16*>(smem);                             // [65][ldx]
     h16* U = Xs + 65 * ldx;                                             // union region
     h16* Ss = U;                                                        // [65][ldx] (input staging uses pitch ldi)
@@ -673,15 +683,17 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 // parameter stage of this chunk (the previous chunk's phase 3 no longer reads Pf / Pdw: barrier at its end)
                 for (int i = tid; i < chunk; i += 512) { sb1[i] = wf[bd.b1 + ch0 + i]; sb2[i] = wf[bd.b2 + ch0 + i]; }
                 for (int i = tid; i < chunk * kk * kk; i += 512) Pdw[i] = wh[bd.dw + (size_t)ch0 * kk * kk + i];
+                const int copTiles = cop >> 5, tiles = (chunk >> 5) * 2, ct0 = ch0 >> 5;
                 __syncthreads();
                 HM_STAMP();   // parameters staged (+ ECA)
                 // phase 1 — 1x1 expand, transposed: Y1[ch][sq] = relu(W1^T x^T + b1); tiles = (chunk/32) x 2 over 8 waves
                 {
-                    const int copTiles = cop >> 5, tiles = (chunk >> 5) * 2, ct0 = ch0 >> 5;
+                    // (one wave per channel tile for both square halves — every W1 fragment fetched once per workgroup — was
+                    // measured: the expand phase went from 12 k to 33 k cycles per chunk; kept: one 32x32 tile per call)
                     const h16* brow = Xs + sqL * ldx + kh;              // tile's square half = t & 1 == stile when t = wave + 8i
                     for (int t = wave; t < tiles; t += 8) {
                         const int ct = t >> 1;                          // (t & 1) == (wave & 1) == stile
-                        const floatx16 e = gemm_tile<true>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+                        const floatx16 e = gemm_tile<true, NPF>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
 #pragma unroll
                         for (int rg = 0; rg < 16; ++rg) {
                             const int ch = ct * 32 + drow(rg, lane);
@@ -691,7 +703,9 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 }
                 __syncthreads();
                 HM_STAMP();   // expand done
-                // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows)
+                // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows).  (Requesting the projection's
+                // first weight fragments before it was measured: the queue held across the depthwise arithmetic spills, 0.79 -> 1.03 ms.)
+                const h16* w2c = wh + bd.w2 + (size_t)(ch0 >> 4) * ctiles * 512;
                 for (int item = tid; item < chunk * 4; item += 512) {
                     const int ch = item % chunk, g = item / chunk;
                     const h16* wd = Pdw + (size_t)ch * kk * kk;
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 for (int i = 0; i < TPW; ++i) {
                     const int ctile = (wave + 8 * i) >> 1;
                     if (ctile < ctiles)
-                        pacc[i] = gemm_tile<false>(pacc[i], Y2 + sqL * ld2 + kh, chunk >> 4, wh + bd.w2 + (size_t)(ch0 >> 4) * ctiles * 512, ctiles, ctile, lane);
+                        pacc[i] = gemm_tile<false, NPF>(pacc[i], Y2 + sqL * ld2 + kh, chunk >> 4, w2c, ctiles, ctile, lane);
                 }
                 // (no barrier here: the next chunk's parameter stage and expand phase touch Pf / Pdw / Y1, which this phase does
                 // not read, and its depthwise phase — the next writer of Y2 — starts behind the barrier after its expand phase)
@@ -731,7 +745,7 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
         {
             const int cv = nd.cv;
             if (wave < 2) {
-                const floatx16 e = gemm_tile<true>(zero16(), Xs + sqL * ldx + kh, C >> 4, wh + nd.v_w, 1, 0, lane);
+                const floatx16 e = gemm_tile<true, NPF>(zero16(), Xs + sqL * ldx + kh, C >> 4, wh + nd.v_w, 1, 0, lane);
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const int ch = drow(rg, lane);
