@@ -2323,7 +2323,7 @@ int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw
     HIPCHK(hipMemcpy(sp->d_mask, profiles, sp->nGames, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_pw_sel, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, sp->d_mask);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -2340,7 +2340,7 @@ int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask) {
     if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, sp->nGames, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_games, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_boards, mask ? sp->d_mask : nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -2491,7 +2491,7 @@ int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out
     if (boards) HIPCHK(hipMemcpy(boards, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToHost));
     if (flags) HIPCHK(hipMemcpy(flags, sp->d_flags, 4 * G_, hipMemcpyDeviceToHost));
     if (d_boards_out) HIPCHK(hipMemcpy(d_boards_out, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToDevice));
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -2542,7 +2542,7 @@ int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_k
     if (!n) return 0;
     hipLaunchKernelGGL(k_rules_probe, dim3((unsigned)std::min<size_t>(n, 4096)), dim3(64), 0, 0, g_rules_dev, d_boards, (int)n, d_out, d_keys);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
 

@@ -312,7 +312,7 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         (void)hipMemsetAsync(s->d_rows[0], 0, sizeof(int32_t) * s->G, nullptr);      // nothing collected yet for this search
         (void)hipMemsetAsync(s->d_rows[1], 0, sizeof(int32_t) * s->G, nullptr);
         if (s->net2) for (int k = 0; k < 4; ++k) (void)hipMemsetAsync(s->d_rowsNet[k >> 1][k & 1], 0, sizeof(int32_t) * s->G, nullptr);
-        (void)hipDeviceSynchronize();              // the prologue ran on the null stream
+        (void)hipStreamSynchronize(nullptr);      // the prologue ran on the null stream
     }
     // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
