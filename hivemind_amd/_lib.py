@@ -52,6 +52,7 @@ _SIGS = {
     "hm_count_moves": (_i, [_vp, _sz, _vp, _vp]),
     "hm_make_moves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "hm_perft": (_i, [_vp, _i, _i, _i, _u64p, C.POINTER(C.c_double)]),
+    "hm_hash_evaluator": (_i, [_vp, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hm_net_create": (_i, [_vp, _sz, _vp, _vp, C.POINTER(_vp)]),
     "hm_net_create_host": (_i, [_vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
     "hm_net_destroy": (_i, [_vp]),

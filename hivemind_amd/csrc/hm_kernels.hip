@@ -635,3 +635,53 @@ int hm_perft(const hm_board* root, int depth, int shard, int nshards, uint64_t* 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Deterministic stand-in network for parity runs at full size (tests / tools only): FNV-1a of a row's 4736 fp16 words
+// (xor salt) seeds a splitmix64 stream whose draws, quantised to 1e-3 and rounded to fp16, fill the five heads — the same
+// function as the oracle's hash_evaluator_salted (oracle/search.hpp), so GPU self-play and the CPU restatement can be
+// compared byte for byte without shipping planes to the host on every lockstep iteration.  One block per row.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long hash_draw(unsigned long long seed, unsigned long long call) {   // the (call+1)-th draw
+    unsigned long long z = seed + (call + 1ULL) * 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint16_t f16_bits_rn(float f) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
+__global__ __launch_bounds__(256) void hash_evaluator_kernel(const uint16_t* __restrict__ planes, int rows, unsigned long long salt, uint16_t* value,
+                                                             uint16_t* piA, uint16_t* piB, uint16_t* wdl, uint16_t* ml) {
+    __shared__ unsigned long long s_seed;
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    if (threadIdx.x == 0) {
+        unsigned long long h = 0xcbf29ce484222325ULL ^ salt;
+        const uint16_t* p = planes + (size_t)row * HM_PLANE_VALUES;
+        for (int k = 0; k < HM_PLANE_VALUES; ++k) { h ^= p[k]; h *= 0x100000001b3ULL; }
+        s_seed = h;
+    }
+    __syncthreads();
+    const unsigned long long seed = s_seed;
+    auto q = [&](unsigned long long call, int lo, int hi) { return (float)(lo + (int)(hash_draw(seed, call) % (unsigned long long)(hi - lo))) * 0.001f; };
+    if (threadIdx.x == 0) {
+        value[row] = f16_bits_rn(q(0, -900, 901));
+        for (int k = 0; k < 3; ++k) wdl[(size_t)row * 3 + k] = f16_bits_rn(q(1 + k, -2000, 2001));
+        ml[row] = f16_bits_rn(q(4, 0, 1001));
+    }
+    for (int k = threadIdx.x; k < HM_POLICY_VALUES; k += 256) {
+        const unsigned long long r = hash_draw(seed, 5ULL + (unsigned long long)k);
+        piA[(size_t)row * HM_POLICY_VALUES + k] = f16_bits_rn((float)((int)(r % 8001ULL) - 4000) * 0.001f);
+        piB[(size_t)row * HM_POLICY_VALUES + k] = f16_bits_rn((float)((int)((r >> 32) % 8001ULL) - 4000) * 0.001f);
+    }
+}
+
+extern "C" int hm_hash_evaluator(const void* d_planes, int rows, uint64_t salt, void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl,
+                                 void* d_moves_left, void* stream) {
+    if (!d_planes || !d_value || !d_pi_a || !d_pi_b || !d_wdl || !d_moves_left || rows < 0) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(hash_evaluator_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint16_t*>(d_planes), rows,
+                       (unsigned long long)salt, static_cast<uint16_t*>(d_value), static_cast<uint16_t*>(d_pi_a), static_cast<uint16_t*>(d_pi_b),
+                       static_cast<uint16_t*>(d_wdl), static_cast<uint16_t*>(d_moves_left));
+    if (hipGetLastError() != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hash_evaluator_kernel launch failed");
+    return 0;
+}

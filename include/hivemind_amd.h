@@ -230,6 +230,10 @@ int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_
 /* Test hook: Board::is_checkmate x4, in-check x2, classify_terminal_position x2 and hash keys for
  * history-free boards (d_out: n*8 ints, d_keys: n*4 u64: hash_key(adv=0), hash_key(adv=1), repetition keys). */
 int hm_rules_probe(const hm_board* d_boards, size_t n, int* d_out, uint64_t* d_keys);
+/* Deterministic stand-in network for full-size parity runs (tests / tools): a hash of each row's planes fills the five fp16
+ * heads — the same function as the CPU restatement's hash evaluator (oracle/search.hpp), `salt` selects one of many. */
+int hm_hash_evaluator(const void* d_planes, int rows, uint64_t salt, void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl,
+                      void* d_moves_left, void* stream);
 /* Test hook: classify_terminal_position (searchthread.cc:101-139), Board::is_draw(ply) and repetition_count on every
  * game's CURRENT position with its real game history.  args4[g] = {teamToPlay, rootTeam, rootAdv, searchPly} (host);
  * out4[g] = {outcome | endInPly << 8, is_draw, repetition_count(A), repetition_count(B)} (host). */

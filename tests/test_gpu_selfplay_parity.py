@@ -135,3 +135,64 @@ def test_empty_game_slots_are_skipped(hm):
     rec2, cnt2 = sp2.records()
     sp2.close()
     assert cnt2 == cnt and rec2.tobytes() == rec.tobytes()
+
+
+class DeviceHashNet:
+    """The same stand-in network evaluated on the device (hm_hash_evaluator): no host round trip per lockstep iteration, so a
+    run at BASELINE's full size finishes in seconds."""
+    native = False
+
+    def __init__(self, hm, salt=0):
+        self.hm, self.salt = hm, salt
+
+    def __call__(self, planes):
+        n = planes.shape[0]
+        f16 = dict(dtype=torch.float16, device=planes.device)
+        out = (torch.empty(n, **f16), torch.empty((n, 4672), **f16), torch.empty((n, 4672), **f16), torch.empty((n, 3), **f16), torch.empty(n, **f16))
+        self.hm.check(self.hm.lib.hm_hash_evaluator(planes.data_ptr(), n, self.salt, *[t.data_ptr() for t in out], None))
+        return out
+
+
+def test_device_hash_evaluator_equals_oracle(hm):
+    boards = O.random_positions(99, 300, 90)
+    planes = hm.board_to_planes(hm.to_device(boards), "f16")
+    for salt in (0, 0x5EED, 2**63 + 12345):
+        got = DeviceHashNet(hm, salt)(planes)
+        want = O.hash_evaluator_salted(planes.cpu().numpy().view(np.uint16).reshape(-1, 4736), salt)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy().view(np.uint16).reshape(w.shape), w)
+
+
+def test_selfplay_full_size_config2_sampled_games_match_oracle(hm, tmp_path):
+    """BASELINE configs[2] at its full size — 64 games, nodes 400, 64 slots, every default of tools/selfplay.h — under the
+    stand-in network: the records of sampled games (first, last, the longest and a short one) equal the sequential CPU
+    restatement byte for byte, i.e. visit counts, sampled actions, outcomes and plane records of whole games match."""
+    kw = dict(games=64, nodes=400, seed=20260, concurrent_games=64)
+    sp = hm.SelfPlay(hm.default_selfplay_config(**kw), DeviceHashNet(hm))
+    res = sp.run()
+    rec, cnt = sp.records()
+    sp.close()
+    assert res.games == 64 and res.samples == cnt > 64 * 10
+    got = _split_by_game(hm, tmp_path, rec, cnt, "full.hvm")
+    sizes = sorted((len(v), g) for g, v in got.items())
+    picks = sorted({0, 63, sizes[-1][1], sizes[len(sizes) // 4][1]})
+    ora = O.SelfPlayOracle(O.selfplay_cfg(**kw), 1, 1)
+    for g in picks:
+        want, info, _ = ora.game(g)
+        assert got.get(g, b"") == want, (g, info, len(got.get(g, b"")), len(want))
+
+
+def test_selfplay_nodes1600_config4_sampled_games_match_oracle(hm, tmp_path):
+    """BASELINE configs[4]'s search shape — nodes 1600, transposition-sharing MCGS, Dirichlet root noise (all defaults) — over
+    whole games: two sampled games of a 12-game run equal the CPU restatement byte for byte."""
+    kw = dict(games=12, nodes=1600, seed=404, concurrent_games=12, max_macro_plies=60)
+    sp = hm.SelfPlay(hm.default_selfplay_config(**kw), DeviceHashNet(hm))
+    res = sp.run()
+    rec, cnt = sp.records()
+    sp.close()
+    assert res.games == 12
+    got = _split_by_game(hm, tmp_path, rec, cnt, "n1600.hvm")
+    ora = O.SelfPlayOracle(O.selfplay_cfg(**kw), 1, 1)
+    for g in (3, 11):
+        want, info, _ = ora.game(g)
+        assert got.get(g, b"") == want, (g, info, len(got.get(g, b"")), len(want))
