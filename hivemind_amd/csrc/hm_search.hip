@@ -2155,6 +2155,7 @@ struct hm_sp {
     u64* d_seed;
     uint8_t* d_mask;
     u32 *d_moveA, *d_moveB;
+    int* d_applyErr;
     hm_board* d_boards;
     int* d_flags;
     RawOut raw;
@@ -2163,6 +2164,13 @@ struct hm_sp {
     std::vector<u64> h_rootHash;
     float pwExponent = 0.4f, altPw = -1.0f, altRootPw = -1.0f;
     int *d_pwRootAlt = nullptr, *d_pwNodeAlt = nullptr;
+    // Per-ply traffic with the host goes through two pinned staging blocks and contiguous device blocks: one copy per call
+    // and direction instead of one per array (a pageable hipMemcpy costs tens of microseconds before the first byte moves).
+    unsigned char* h_stage = nullptr;      // pinned
+    size_t stageBytes = 0;
+    unsigned char* d_in = nullptr;         // [target G*4 | seed G*8 | mask G | moveA G*4 | moveB G*4 | apply error flag 4] (+ padding)
+    unsigned char* d_out = nullptr;        // RootOut arrays, then boards / flags of hm_sp_game_state
+    size_t inBytes = 0, outRootBytes = 0;  // size of the input block; bytes of d_out up to and including `visits`
 };
 
 #define HIPCHK(expr)                                                                              \
@@ -2288,12 +2296,37 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     pl.rules = g_rules_dev; pl.polNormal = g_polN_dev; pl.polDrop = g_polD_dev;
     RootOut& ro = sp->ro;
     ro.maxEdges = sp->maxEdges;
-    rc |= dalloc(sp, &ro.counts, G_); rc |= dalloc(sp, &ro.moveA, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.moveB, G_ * ro.maxEdges);
-    rc |= dalloc(sp, &ro.visits, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.q, G_ * ro.maxEdges); rc |= dalloc(sp, &ro.prior, G_ * ro.maxEdges);
-    rc |= dalloc(sp, &ro.rootQ, G_); rc |= dalloc(sp, &ro.info, G_ * HM_SP_INFO_INTS);
-    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 2) /* [0] active games, [1] hm_sp_apply error flag */; rc |= dalloc(sp, &sp->d_target, G_);
-    rc |= dalloc(sp, &sp->d_seed, G_); rc |= dalloc(sp, &sp->d_mask, G_); rc |= dalloc(sp, &sp->d_moveA, G_); rc |= dalloc(sp, &sp->d_moveB, G_);
-    rc |= dalloc(sp, &sp->d_boards, G_); rc |= dalloc(sp, &sp->d_flags, G_); rc |= dalloc(sp, &sp->d_term, G_);
+    {
+        // device output block: counts | rootQ | info | moveA | moveB | visits || q | prior || boards | flags
+        const size_t E_ = (size_t)ro.maxEdges;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+        const size_t oCounts = carve(4 * G_), oRootQ = carve(4 * G_), oInfo = carve(4 * G_ * HM_SP_INFO_INTS);
+        const size_t oMoveA = carve(4 * G_ * E_), oMoveB = carve(4 * G_ * E_), oVisits = carve(4 * G_ * E_);
+        sp->outRootBytes = off;
+        const size_t oQ = carve(4 * G_ * E_), oPrior = carve(4 * G_ * E_), oBoards = carve(sizeof(hm_board) * G_), oFlags = carve(4 * G_);
+        rc |= dalloc(sp, &sp->d_out, off);
+        if (rc) { hm_sp_destroy(sp); return rc; }
+        unsigned char* b = sp->d_out;
+        ro.counts = reinterpret_cast<int*>(b + oCounts); ro.rootQ = reinterpret_cast<float*>(b + oRootQ); ro.info = reinterpret_cast<int*>(b + oInfo);
+        ro.moveA = reinterpret_cast<u32*>(b + oMoveA); ro.moveB = reinterpret_cast<u32*>(b + oMoveB); ro.visits = reinterpret_cast<int*>(b + oVisits);
+        ro.q = reinterpret_cast<float*>(b + oQ); ro.prior = reinterpret_cast<float*>(b + oPrior);
+        sp->d_boards = reinterpret_cast<hm_board*>(b + oBoards); sp->d_flags = reinterpret_cast<int*>(b + oFlags);
+        // device input block: target | seed | mask | moveA | moveB | apply error flag
+        size_t in = 0;
+        auto carveIn = [&](size_t bytes) { const size_t o = in; in += (bytes + 15) & ~(size_t)15; return o; };
+        const size_t iSeed = carveIn(8 * G_), iTarget = carveIn(4 * G_), iMask = carveIn(G_), iMoveA = carveIn(4 * G_), iMoveB = carveIn(4 * G_), iErr = carveIn(4);
+        sp->inBytes = in;
+        rc |= dalloc(sp, &sp->d_in, in);
+        if (rc) { hm_sp_destroy(sp); return rc; }
+        sp->d_seed = reinterpret_cast<u64*>(sp->d_in + iSeed); sp->d_target = reinterpret_cast<int*>(sp->d_in + iTarget);
+        sp->d_moveA = reinterpret_cast<u32*>(sp->d_in + iMoveA); sp->d_moveB = reinterpret_cast<u32*>(sp->d_in + iMoveB);
+        sp->d_mask = sp->d_in + iMask; sp->d_applyErr = reinterpret_cast<int*>(sp->d_in + iErr);
+        sp->stageBytes = std::max(off, in);
+        if (hipHostMalloc(reinterpret_cast<void**>(&sp->h_stage), sp->stageBytes, hipHostMallocDefault) != hipSuccess) { hm_sp_destroy(sp); return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed"); }
+    }
+    rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 2) /* [0] active games */;
+    rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
     rc |= dalloc(sp, &sp->raw.caps, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.counts, G_ * 2); rc |= dalloc(sp, &sp->raw.onTurn, G_ * 2);
     if (rc) { hm_sp_destroy(sp); return rc; }
@@ -2329,6 +2362,7 @@ int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw
 
 int hm_sp_destroy(hm_sp* sp) {
     if (!sp) return 0;
+    if (sp->h_stage) (void)hipHostFree(sp->h_stage);
     for (void* p : sp->allocs) (void)hipFree(p);
     delete sp;
     return 0;
@@ -2365,23 +2399,27 @@ static void fill_noise(hm_sp* sp, const uint64_t* seeds, float alpha, std::vecto
 int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask) {
     if (!sp || !target_nodes) return hm_fail(HM_ERR_INVALID, "null argument");
     const int G_ = sp->nGames;
-    HIPCHK(hipMemcpy(sp->d_target, target_nodes, sizeof(int) * G_, hipMemcpyHostToDevice));
-    std::vector<uint64_t> seeds(G_, 0);
-    if (noise_seeds) seeds.assign(noise_seeds, noise_seeds + G_);
-    HIPCHK(hipMemcpy(sp->d_seed, seeds.data(), 8 * (size_t)G_, hipMemcpyHostToDevice));
-    if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
+    // seeds | targets | mask are adjacent in the input block: one staged upload
+    unsigned char* hs = sp->h_stage;
+    uint64_t* seeds = reinterpret_cast<uint64_t*>(hs + (reinterpret_cast<unsigned char*>(sp->d_seed) - sp->d_in));
+    if (noise_seeds) std::memcpy(seeds, noise_seeds, 8 * (size_t)G_); else std::memset(seeds, 0, 8 * (size_t)G_);
+    std::memcpy(hs + (reinterpret_cast<unsigned char*>(sp->d_target) - sp->d_in), target_nodes, sizeof(int) * (size_t)G_);
+    if (mask) std::memcpy(hs + (sp->d_mask - sp->d_in), mask, (size_t)G_);
+    const size_t upTo = (size_t)(sp->d_mask - sp->d_in) + (size_t)G_;
+    HIPCHK(hipMemcpy(sp->d_in, hs, upTo, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_begin, dim3(G_), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, alpha, eps, mask ? sp->d_mask : nullptr, sp->d_rootHash);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(sp->h_rootHash.data(), sp->d_rootHash, 16 * (size_t)G_, hipMemcpyDeviceToHost));
     if (alpha > 0.0f && eps > 0.0f) {
+        std::vector<uint64_t> seedCopy(seeds, seeds + G_);       // the staging block is reused by the download below
+        HIPCHK(hipMemcpy(hs, sp->d_rootHash, 16 * (size_t)G_, hipMemcpyDeviceToHost));
+        std::memcpy(sp->h_rootHash.data(), hs, 16 * (size_t)G_);
         std::vector<float> nz;
-        fill_noise(sp, seeds.data(), alpha, nz);
+        fill_noise(sp, seedCopy.data(), alpha, nz);
         HIPCHK(hipMemcpy(sp->pl.noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     sp->alpha = alpha; sp->eps = eps;
     return 0;
 }
-
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
@@ -2412,14 +2450,17 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     const size_t G_ = sp->nGames, E = (size_t)sp->maxEdges;
     hipLaunchKernelGGL(k_root_stats, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->ro);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(counts, sp->ro.counts, 4 * G_, hipMemcpyDeviceToHost));
-    if (move_a) HIPCHK(hipMemcpy(move_a, sp->ro.moveA, 4 * G_ * E, hipMemcpyDeviceToHost));
-    if (move_b) HIPCHK(hipMemcpy(move_b, sp->ro.moveB, 4 * G_ * E, hipMemcpyDeviceToHost));
-    if (visits) HIPCHK(hipMemcpy(visits, sp->ro.visits, 4 * G_ * E, hipMemcpyDeviceToHost));
+    // counts | rootQ | info | moveA | moveB | visits are one device block: one download into the pinned stage
+    HIPCHK(hipMemcpy(sp->h_stage, sp->d_out, sp->outRootBytes, hipMemcpyDeviceToHost));
+    auto at = [&](const void* dev) { return sp->h_stage + (static_cast<const unsigned char*>(dev) - sp->d_out); };
+    std::memcpy(counts, at(sp->ro.counts), 4 * G_);
+    if (move_a) std::memcpy(move_a, at(sp->ro.moveA), 4 * G_ * E);
+    if (move_b) std::memcpy(move_b, at(sp->ro.moveB), 4 * G_ * E);
+    if (visits) std::memcpy(visits, at(sp->ro.visits), 4 * G_ * E);
+    if (root_q) std::memcpy(root_q, at(sp->ro.rootQ), 4 * G_);
+    if (info) std::memcpy(info, at(sp->ro.info), 4 * G_ * HM_SP_INFO_INTS);
     if (q) HIPCHK(hipMemcpy(q, sp->ro.q, 4 * G_ * E, hipMemcpyDeviceToHost));
     if (prior) HIPCHK(hipMemcpy(prior, sp->ro.prior, 4 * G_ * E, hipMemcpyDeviceToHost));
-    if (root_q) HIPCHK(hipMemcpy(root_q, sp->ro.rootQ, 4 * G_, hipMemcpyDeviceToHost));
-    if (info) HIPCHK(hipMemcpy(info, sp->ro.info, 4 * G_ * HM_SP_INFO_INTS, hipMemcpyDeviceToHost));
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
@@ -2471,30 +2512,38 @@ int hm_sp_active(hm_sp* sp, int* active) {
 int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
     if (!sp || !move_a || !move_b) return hm_fail(HM_ERR_INVALID, "null argument");
     const size_t G_ = sp->nGames;
-    HIPCHK(hipMemcpy(sp->d_moveA, move_a, 4 * G_, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sp->d_moveB, move_b, 4 * G_, hipMemcpyHostToDevice));
-    if (mask) HIPCHK(hipMemcpy(sp->d_mask, mask, G_, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(sp->d_active + 1, 0, sizeof(int)));
-    hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr, sp->d_active + 1);
+    // mask | moveA | moveB | error flag (cleared) are adjacent in the input block: one staged upload
+    unsigned char* hs = sp->h_stage;
+    const size_t from = (size_t)(sp->d_mask - sp->d_in);
+    if (mask) std::memcpy(hs + from, mask, G_);
+    std::memcpy(hs + (reinterpret_cast<unsigned char*>(sp->d_moveA) - sp->d_in), move_a, 4 * G_);
+    std::memcpy(hs + (reinterpret_cast<unsigned char*>(sp->d_moveB) - sp->d_in), move_b, 4 * G_);
+    std::memset(hs + (reinterpret_cast<unsigned char*>(sp->d_applyErr) - sp->d_in), 0, 4);
+    HIPCHK(hipMemcpy(sp->d_in + from, hs + from, sp->inBytes - from, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr, sp->d_applyErr);
     HIPCHK(hipGetLastError());
-    int err = 0;
-    HIPCHK(hipMemcpy(&err, sp->d_active + 1, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
+    int* err = reinterpret_cast<int*>(hs);
+    HIPCHK(hipMemcpy(err, sp->d_applyErr, sizeof(int), hipMemcpyDeviceToHost));
+    if (*err) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
     return 0;
 }
-
 int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out) {
     if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
     const size_t G_ = sp->nGames;
     hipLaunchKernelGGL(k_game_state, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_boards, sp->d_flags);
     HIPCHK(hipGetLastError());
-    if (boards) HIPCHK(hipMemcpy(boards, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToHost));
-    if (flags) HIPCHK(hipMemcpy(flags, sp->d_flags, 4 * G_, hipMemcpyDeviceToHost));
-    if (d_boards_out) HIPCHK(hipMemcpy(d_boards_out, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToDevice));
+    if (d_boards_out) HIPCHK(hipMemcpyAsync(d_boards_out, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToDevice, nullptr));
+    if (boards || flags) {
+        // boards | flags are adjacent at the end of the output block: one download
+        const unsigned char* from = reinterpret_cast<const unsigned char*>(sp->d_boards);
+        const size_t bytes = (size_t)(reinterpret_cast<const unsigned char*>(sp->d_flags) - from) + 4 * G_;
+        HIPCHK(hipMemcpy(sp->h_stage, from, bytes, hipMemcpyDeviceToHost));
+        if (boards) std::memcpy(boards, sp->h_stage, sizeof(hm_board) * G_);
+        if (flags) std::memcpy(flags, sp->h_stage + (reinterpret_cast<const unsigned char*>(sp->d_flags) - from), 4 * G_);
+    }
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
-
 int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps, int* counts, uint8_t* on_turn) {
     if (!sp || !d_pi_a || !d_pi_b || !moves || !probs || !counts) return hm_fail(HM_ERR_INVALID, "null argument");
     const size_t G_ = sp->nGames;
