@@ -1725,13 +1725,28 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         for (int i = lane; i < nB; i += 64) flB[i] = (gives_check(rt, p.jb.bd[1], lb[i]) ? 1u : 0u) | (is_capture(p.jb.bd[1], lb[i]) ? 2u : 0u);
         __builtin_amdgcn_wave_barrier();
         {
-            int k = 0;
-            for (int i = 0; i < nA; ++i) if (flA[i] & 1) ord[k++] = (u32)i;
-            for (int i = 0; i < nA; ++i) if (!(flA[i] & 1)) ord[k++] = (u32)i;
-            for (int i = nA; i < HM_MAX_MOVES; ++i) if (i < nB) ord[i] = 0;
-            k = 0;
-            for (int i = 0; i < nB; ++i) if (flB[i] & 1) { ord[k] = (ord[k] & 0xffffu) | ((u32)i << 16); k++; }
-            for (int i = 0; i < nB; ++i) if (!(flB[i] & 1)) { ord[k] = (ord[k] & 0xffffu) | ((u32)i << 16); k++; }
+            // stable_partition by "gives check" (agent.cc:150-158), lane-parallel: checking moves first, each group in list order
+            auto partition = [&](const u32* fl, int n, bool high) {
+                int nChk = 0;
+                for (int c0 = 0; c0 < n; c0 += 64) nChk += __popcll(__ballot(c0 + lane < n && (fl[c0 + lane] & 1)));
+                int pc = 0, pn = nChk;
+                const u64 below = (1ULL << lane) - 1ULL;
+                for (int c0 = 0; c0 < n; c0 += 64) {
+                    const int i = c0 + lane;
+                    const bool in = i < n, chk = in && (fl[i] & 1);
+                    const u64 mC = __ballot(chk), mN = __ballot(in && !chk);
+                    if (in) {
+                        const int pos = chk ? pc + __popcll(mC & below) : pn + __popcll(mN & below);
+                        ord[pos] = high ? (ord[pos] & 0xffffu) | ((u32)i << 16) : (u32)i;
+                    }
+                    pc += __popcll(mC); pn += __popcll(mN);
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            partition(flA, nA, false);
+            for (int i = nA + lane; i < nB; i += 64) ord[i] = 0;
+            __builtin_amdgcn_wave_barrier();
+            partition(flB, nB, true);
         }
         __builtin_amdgcn_wave_barrier();
         const int victim = team ^ 1;
@@ -1749,26 +1764,43 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
             const int total = phase == 0 ? nA : phase == 1 ? nB : nA * nB;
             if (lane == 0) *hitCount = 0;
             __builtin_amdgcn_wave_barrier();
-            for (int t = lane; t < total; t += 64) {
-                u32 mA = 0, mB = 0;
-                bool consider;
+            // Two passes per window of 1024 candidates: the cheap admission test (gives check / a board already in check, sit
+            // rules) first, its survivors compacted, then the expensive joint make + "victim has a board without a legal move"
+            // on densely packed lanes — few candidates pass the first test, and a wave pays for its slowest lane.
+            u32* cand = L.helperLists[0];                                  // 1024 entries (helperLists[0..1] are contiguous)
+            auto admit = [&](int t) {
                 if (phase == 0) {
                     const int i = (int)(ord[t] & 0xffffu);
-                    mA = la[i];
-                    consider = (aChk || bChk || (flA[i] & 1)) && (!bOn || is_single_pass_legal(adv, aOn, bOn, (flA[i] & 2) != 0));
-                } else if (phase == 1) {
-                    const int i = (int)(ord[t] >> 16);
-                    mB = lb[i];
-                    consider = (aChk || bChk || (flB[i] & 1)) && (!aOn || is_single_pass_legal(adv, aOn, bOn, (flB[i] & 2) != 0));
-                } else {
-                    const int i = (int)(ord[t / nB] & 0xffffu), j = (int)(ord[t % nB] >> 16);
-                    mA = la[i]; mB = lb[j];
-                    consider = aChk || bChk || (flA[i] & 1) || (flB[j] & 1);
+                    return (aChk || bChk || (flA[i] & 1)) && (!bOn || is_single_pass_legal(adv, aOn, bOn, (flA[i] & 2) != 0));
                 }
-                if (!consider) continue;
-                P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
-                make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
-                if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; else atomicOr(&gm.overflow, 32); }   // candidate list truncated
+                if (phase == 1) {
+                    const int i = (int)(ord[t] >> 16);
+                    return (aChk || bChk || (flB[i] & 1)) && (!aOn || is_single_pass_legal(adv, aOn, bOn, (flB[i] & 2) != 0));
+                }
+                const int i = (int)(ord[t / nB] & 0xffffu), j = (int)(ord[t % nB] >> 16);
+                return aChk || bChk || (flA[i] & 1) || (flB[j] & 1);
+            };
+            for (int w0 = 0; w0 < total; w0 += 1024) {
+                int nc = 0;
+                for (int t0 = w0; t0 < min(total, w0 + 1024); t0 += 64) {
+                    const int t = t0 + lane;
+                    const bool ok = t < total && admit(t);
+                    const u64 m = __ballot(ok);
+                    if (ok) cand[nc + __popcll(m & ((1ULL << lane) - 1ULL))] = (u32)t;
+                    nc += __popcll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int c = lane; c < nc; c += 64) {
+                    const int t = (int)cand[c];
+                    u32 mA = 0, mB = 0;
+                    if (phase == 0) mA = la[ord[t] & 0xffffu];
+                    else if (phase == 1) mB = lb[ord[t] >> 16];
+                    else { mA = la[ord[t / nB] & 0xffffu]; mB = lb[ord[t % nB] >> 16]; }
+                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                    make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
+                    if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; else atomicOr(&gm.overflow, 32); }   // candidate list truncated
+                }
+                __builtin_amdgcn_wave_barrier();
             }
             __builtin_amdgcn_wave_barrier();
             int nh = (int)*hitCount;
