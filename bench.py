@@ -240,7 +240,7 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this workload (WRITE_SIZE + 2 x FETCH_SIZE,
         # separate passes; profiles/r01_selfplay64_pmc_hbm.json) - PMC counters cannot be read from inside the bench
         pmc = _pmc_traffic(PMC_SELFPLAY) if (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
-        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward_kernel")):
+        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward")):
             hit = [k for k in pmc if k.startswith(key)]
             if hit:
                 r_["traffic"] = sum(pmc[k] for k in hit)

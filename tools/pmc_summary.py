@@ -45,7 +45,7 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
-    ap.add_argument("--kernels", default="k_collect,k_process,k_begin,rise_forward_kernel,encode_planes_kernel,perft", help="substrings to keep")
+    ap.add_argument("--kernels", default="k_collect,k_process,k_begin,rise_forward,encode_planes_kernel,perft", help="substrings to keep")
     a = ap.parse_args()
     keep = [s for s in a.kernels.split(",") if s]
     acc = {}
