@@ -241,7 +241,7 @@ def main():
         # separate passes; profiles/r01_selfplay64_pmc_hbm.json) - PMC counters cannot be read from inside the bench
         pmc = _pmc_traffic(PMC_SELFPLAY) if (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
         for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward")):
-            hit = [k for k in pmc if k.startswith(key)]
+            hit = [k for k in pmc if key in k]
             if hit:
                 r_["traffic"] = sum(pmc[k] for k in hit)
                 r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"

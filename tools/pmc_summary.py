@@ -35,6 +35,9 @@ def source_hash(root=ROOT):
 
 
 def short_name(k):
+    m = re.match(r"_ZN3hmn19rise_forward_narrowILi(\d+)ELb(\d)EE", k.strip())     # rocprofv3 leaves this template mangled
+    if m:
+        return f"rise_forward_narrow<{m.group(1)},{'true' if m.group(2) == '1' else 'false'}>"
     k = re.sub(r"\(.*\)$", "", k.strip())
     k = re.sub(r"^void ", "", k)
     return k.replace("hms::", "").replace("hmn::", "").replace("hmd::", "")
