@@ -22,6 +22,7 @@ from .selfplay import (SelfPlay, SelfPlayConfig, default_selfplay_config, gather
                        write_chunk)
 from .tournament import (Tournament, TournamentConfig, TournamentResult, default_tournament_config,  # noqa: E402,F401
                          move_uci, statistics as tournament_statistics)
+from .uci import Uci  # noqa: E402,F401
 
 _TORCH_DT = {DT_F16: torch.float16, DT_F32: torch.float32, DT_U8: torch.uint8}
 _NAME_DT = {"f16": DT_F16, "f32": DT_F32, "u8": DT_U8, torch.float16: DT_F16,

@@ -1931,6 +1931,10 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         int* inf = o.info + (size_t)g * HM_SP_INFO_INTS;
         inf[12] = gm.root >= 0 ? best_move_index(s, s.nodes[gm.root], prm.qVetoDelta, prm.qValueWeight) : -1;
         inf[13] = gm.listWords; inf[14] = inf[15] = 0;
+        if (inf[12] >= 0 && gm.root >= 0 && (s.nodes[gm.root].flags & F_EXPANDED) && inf[12] < s.nodes[gm.root].expanded) {
+            const Node& bc = s.nodes[edges_of(s, s.nodes[gm.root])[inf[12]].child];    // for format_uci_score (agent.cc:48-78)
+            inf[14] = bc.type; inf[15] = bc.endInPly;
+        }
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
         inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;
@@ -1958,6 +1962,18 @@ __global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* m
     s.g->hlen[0] = p.jb.hlen[0]; s.g->hlen[1] = p.jb.hlen[1];
     s.g->prefix[0] = p.jb.prefix[0]; s.g->prefix[1] = p.jb.prefix[1];
     s.g->team ^= 1; s.g->adv ^= 1;
+}
+
+// side to act of every game slot, without touching positions or history (the UCI front end replays single-board moves with
+// hm_sp_apply, which flips the side per call, and then sets Team / Mode as the options say: uci.cc:283-296)
+__global__ void k_set_side(Pools pl, int n, const uint8_t* team, const uint8_t* adv) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) { pl.games[g].team = team[g] ? 1 : 0; pl.games[g].adv = adv[g] ? 1 : 0; }
+}
+// ends the search of the masked games at their next collect (Agent::set_is_running(false), agent.h: the UCI `stop` / movetime path)
+__global__ void k_stop(Pools pl, int n, const uint8_t* mask) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n && (!mask || mask[g])) pl.games[g].targetNodes = 0;
 }
 
 // (re)start games from a compact board (history restarts, like Board::set)
@@ -2557,6 +2573,25 @@ int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const u
     int* err = reinterpret_cast<int*>(hs);
     HIPCHK(hipMemcpy(err, sp->d_applyErr, sizeof(int), hipMemcpyDeviceToHost));
     if (*err) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
+    return 0;
+}
+int hm_sp_set_side(hm_sp* sp, const uint8_t* team, const uint8_t* time_adv) {
+    if (!sp || !team || !time_adv) return hm_fail(HM_ERR_INVALID, "null argument");
+    const size_t G_ = sp->nGames;
+    unsigned char* hs = sp->h_stage;
+    std::memcpy(hs, team, G_); std::memcpy(hs + G_, time_adv, G_);
+    unsigned char* d = reinterpret_cast<unsigned char*>(sp->d_moveA);          // scratch: 8 * G bytes of the input block
+    HIPCHK(hipMemcpy(d, hs, 2 * G_, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_side, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, d, d + G_);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+int hm_sp_stop(hm_sp* sp, const uint8_t* mask, void* stream) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (mask) HIPCHK(hipMemcpyAsync(sp->d_mask, mask, sp->nGames, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    hipLaunchKernelGGL(k_stop, dim3((sp->nGames + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), sp->pl, sp->nGames, mask ? sp->d_mask : nullptr);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out) {

@@ -1,0 +1,370 @@
+// hm_uci.hip — UCI front end over the GPU search engine (host C++ only; compiled by hipcc into the same library).
+//
+// Replaces, behind the C ABI of include/hivemind_amd.h (hm_uci_*), the reference's
+//   UCI::loop / position / go / setoption / send_uci_response / stop / new_game      interface/uci.cc:82-141, 143-231, 239-296,
+//                                                                                    298-317, 396-429
+//   Agent::run_search's budget handling for UCI (`go nodes N`, `go movetime T`),
+//   its final `info ...` line, extract_best_move and format_uci_score                search/agent.cc:48-78, 421-558, 898-1002,
+//                                                                                    1031-1049
+// One game slot of the lockstep engine (hm_sp_*) plays the role of the Agent: `position` replays the move list on the device
+// (history, repetition keys), `go` runs the search and prints the solver-aware best move (get_best_move_idx_with_q_weight,
+// node.h:656-754 — computed on the device, hm_sp_root_stats info[12]).
+// Built: uci, isready, ucinewgame, position startpos|fen ... [moves <1|2><uci> ...], go nodes N | movetime T (| neither = 1 s),
+// stop, setoption name {Team, Mode, DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,
+// PWExponentPermille, Transpositions} (Hash, MultiPV, Ponder are accepted and reported as the reference does), quit.
+// Not built (documented in DESIGN.md): pondering / ponderhit, tree reuse between moves, multi-PV lines and PV extraction
+// beyond the best move, the `policy` debug command, and the movetime heuristics (early stopping, time extension): a movetime
+// search runs until the deadline.  A search is synchronous: the command returns when `bestmove` has been printed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/hivemind_amd.h"
+#include "hm_host.hpp"
+
+const HostTables& hm_host_tables();
+int hm_fail(int code, const std::string& msg);
+
+namespace {
+
+const char* const kStartFen = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1";
+
+std::string uci_text(hm_move m) {
+    char buf[16];
+    hm_move_uci(m, buf, sizeof buf);
+    return buf;
+}
+
+// Position::set (Fairy-Stockfish position.cpp:232-470) for the bughouse subset: placement with '~' promoted markers and the
+// pocket either in [brackets] or after an eighth slash, side, castling, en passant (kept only when a pawn can take,
+// :395-409), halfmove clock, fullmove number.
+bool parse_fen(const HostTables& h, const std::string& fen, hm_pos* out) {
+    hm_pos p;
+    std::memset(&p, 0, sizeof p);
+    p.ep = 64;
+    std::istringstream ss(fen);
+    std::string placement, stm, cast = "-", ep = "-";
+    if (!(ss >> placement >> stm)) return false;
+    static const std::string pcs = " PNBRQK";
+    int s = 56, slashes = 0;
+    size_t i = 0;
+    for (; i < placement.size(); ++i) {
+        const char ch = placement[i];
+        if (ch == '[') break;
+        if (ch >= '0' && ch <= '9') s += ch - '0';
+        else if (ch == '/') { if (++slashes == 8) { ++i; break; } s -= 16; }
+        else {
+            const size_t idx = pcs.find((char)std::toupper((unsigned char)ch));
+            if (idx == std::string::npos || idx == 0) continue;
+            if (s < 0 || s > 63) return false;
+            const uint64_t b = 1ULL << s;
+            p.by_type[idx - 1] |= b;
+            p.by_color[std::islower((unsigned char)ch) ? 1 : 0] |= b;
+            if (i + 1 < placement.size() && placement[i + 1] == '~') { p.promoted |= b; ++i; }
+            ++s;
+        }
+    }
+    for (; i < placement.size(); ++i) {
+        const char ch = placement[i];
+        const size_t idx = pcs.find((char)std::toupper((unsigned char)ch));
+        if (ch == '[' || ch == ']' || idx == std::string::npos || idx == 0 || idx == 6) continue;
+        uint8_t& n = p.hand[std::islower((unsigned char)ch) ? 1 : 0][idx - 1];
+        if (n < 31) ++n;
+    }
+    if (__builtin_popcountll(p.by_type[5] & p.by_color[0]) != 1 || __builtin_popcountll(p.by_type[5] & p.by_color[1]) != 1) return false;
+    p.stm = stm == "b" ? 1 : 0;
+    ss >> std::ws;
+    int r50 = 0, full = 1;
+    if (ss.peek() != EOF && !std::isdigit(ss.peek())) ss >> cast >> ep;
+    ss >> r50 >> full;
+    for (const char ch : cast) {
+        const int c = std::islower((unsigned char)ch) ? 1 : 0;
+        const char up = (char)std::toupper((unsigned char)ch);
+        const int base = c ? 56 : 0;
+        const uint64_t rooks = p.by_type[3] & p.by_color[c], king = p.by_type[5] & p.by_color[c];
+        if (!(king & (1ULL << (base + 4)))) continue;                              // standard chess: king on the e-file
+        if (up == 'K' && (rooks & (1ULL << (base + 7)))) p.castling |= c ? HM_BLACK_OO : HM_WHITE_OO;
+        else if (up == 'Q' && (rooks & (1ULL << base))) p.castling |= c ? HM_BLACK_OOO : HM_WHITE_OOO;
+    }
+    if (ep.size() == 2 && ep[0] >= 'a' && ep[0] <= 'h' && ep[1] >= '1' && ep[1] <= '8') {
+        const int e = (ep[1] - '1') * 8 + (ep[0] - 'a'), us = p.stm, push = us == 0 ? 8 : -8, f = e & 7;
+        const uint64_t occ = p.by_color[0] | p.by_color[1];
+        const uint64_t ourPawns = p.by_type[0] & p.by_color[us], theirPawns = p.by_type[0] & p.by_color[us ^ 1];
+        uint64_t from = 0;                                                          // squares one of our pawns would capture from
+        if (e - push >= 0 && e - push < 64) {
+            if (f > 0) from |= 1ULL << (e - push - 1);
+            if (f < 7) from |= 1ULL << (e - push + 1);
+        }
+        const bool ok = (from & ourPawns) && e - push >= 0 && e - push < 64 && (theirPawns & (1ULL << (e - push)))
+                        && e + push >= 0 && e + push < 64 && !(occ & ((1ULL << e) | (1ULL << (e + push))));
+        p.ep = ok ? (uint8_t)e : 64;
+    }
+    p.rule50 = (uint8_t)std::min(std::max(r50, 0), 255);
+    p.game_ply = (uint16_t)(std::max(2 * (full - 1), 0) + (p.stm ? 1 : 0));
+    p.key = host_compute_key(h, p);
+    *out = p;
+    return true;
+}
+
+std::string trim(const std::string& s) {
+    const size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+
+}  // namespace
+
+struct hm_uci {
+    const hm_net* net = nullptr;
+    hm_eval_fn fn = nullptr;
+    void* user = nullptr;
+    hm_eval_io io{};
+    hm_search_config scfg{};
+    hm_sp* sp = nullptr;
+    int maxNodes = 0;
+    int team = HM_WHITE;
+    bool sit = false;                 // Mode sit = teamHasTimeAdvantage (uci.cc:289-295)
+    int multiPV = 1;
+    bool ponder = true;
+    hm_board board{};                 // host copy of the current game position
+    hm_pos* d_pos = nullptr;          // scratch for legal-move queries
+    hm_move* d_moves = nullptr;
+    uint32_t* d_counts = nullptr;
+    hipStream_t sN = nullptr;
+    std::string out;
+};
+
+static int uci_rebuild_engine(hm_uci* u) {
+    if (u->sp) { hm_sp_destroy(u->sp); u->sp = nullptr; }
+    return hm_sp_create_ex(1, u->maxNodes, 2048, &u->scfg, &u->sp);
+}
+static int uci_sync_board(hm_uci* u) {
+    int flags = 0;
+    return hm_sp_game_state(u->sp, &u->board, &flags, nullptr);
+}
+static int uci_set_position(hm_uci* u, const hm_board& b) {
+    const uint8_t one = 1;
+    if (int rc = hm_sp_set_games(u->sp, &b, &one)) return rc;
+    return uci_sync_board(u);
+}
+// UCI::to_move (Fairy-Stockfish stubs.cpp:61-75): the legal move of board `b` whose text equals `text`
+static int uci_find_move(hm_uci* u, int b, std::string text, hm_move* out) {
+    if (text.size() == 5) {
+        if (text[4] == '=') text.pop_back();
+        else if (text[1] != '@') text[4] = (char)std::tolower((unsigned char)text[4]);
+    }
+    if (hipMemcpy(u->d_pos, &u->board.pos[b], sizeof(hm_pos), hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
+    if (int rc = hm_legal_moves(u->d_pos, 1, u->d_moves, u->d_counts, nullptr)) return rc;
+    uint32_t n = 0;
+    std::vector<hm_move> mv(HM_MAX_MOVES);
+    if (hipMemcpy(&n, u->d_counts, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(mv.data(), u->d_moves, 4 * HM_MAX_MOVES, hipMemcpyDeviceToHost) != hipSuccess)
+        return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
+    *out = 0;
+    for (uint32_t i = 0; i < n && i < HM_MAX_MOVES; ++i)
+        if (uci_text(mv[i]) == text) { *out = mv[i]; break; }
+    return 0;
+}
+
+static void uci_position(hm_uci* u, std::istringstream& is) {   // uci.cc:82-141
+    std::string token;
+    is >> token;
+    hm_board b;
+    std::memset(&b, 0, sizeof b);
+    const HostTables& h = hm_host_tables();
+    std::string fen;
+    if (token == "startpos") { fen = std::string(kStartFen) + "|" + kStartFen; is >> token; }
+    else if (token == "fen") { while (is >> token && token != "moves") fen += token + " "; }
+    else return;
+    const size_t bar = fen.find('|');
+    if (bar == std::string::npos || !parse_fen(h, trim(fen.substr(0, bar)), &b.pos[0]) || !parse_fen(h, trim(fen.substr(bar + 1)), &b.pos[1])) {
+        u->out += "info string position failed: invalid FEN\n";
+        return;
+    }
+    b.rep_count[0] = b.rep_count[1] = 1;
+    b.team = (uint8_t)u->team; b.time_adv = u->sit ? 1 : 0;
+    if (uci_set_position(u, b)) { u->out += std::string("info string position failed: ") + hm_last_error() + "\n"; return; }
+    if (token != "moves") return;
+    int moveCount = 0;
+    while (is >> token) {
+        if (token.empty() || token[0] < '1' || token[0] > '2') {
+            u->out += "info string Error: Invalid board indicator in move '" + token + "' at move " + std::to_string(moveCount + 1) + "\n";
+            break;
+        }
+        const int bd = token[0] - '1';
+        hm_move m = 0;
+        if (uci_find_move(u, bd, token.substr(1), &m) || m == 0) {
+            u->out += "info string Error: Invalid move '" + token.substr(1) + "' on board " + std::to_string(bd + 1) + " at move " + std::to_string(moveCount + 1) + "\n";
+            break;
+        }
+        const hm_move a = bd == 0 ? m : 0, c = bd == 1 ? m : 0;
+        const uint8_t one = 1;
+        if (hm_sp_apply(u->sp, &a, &c, &one) || uci_sync_board(u)) { u->out += std::string("info string position failed: ") + hm_last_error() + "\n"; break; }
+        ++moveCount;
+    }
+}
+
+static std::string uci_score(int childType, int childEndInPly, float q) {   // format_uci_score, agent.cc:48-78 (child of the root)
+    if (childType == 1) return "score mate -" + std::to_string(std::max(1, (childEndInPly + 1) / 2));   // child wins = we are mated
+    if (childType == 2) return "score mate " + std::to_string(std::max(1, (childEndInPly + 1) / 2));    // child loses = we mate
+    return "score cp " + std::to_string(static_cast<int>(180.0f * std::tan(1.56f * q)));
+}
+
+static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Agent::run_search (agent.cc:421-558, 898-1002)
+    std::string token;
+    int moveTime = 0;
+    size_t nodes = 0;
+    while (is >> token) {
+        if (token == "movetime") is >> moveTime;
+        else if (token == "nodes") is >> nodes;
+    }
+    if (nodes == 0 && moveTime <= 0) moveTime = 1000;                               // "Default to 1 second if nothing specified"
+    const uint8_t team = (uint8_t)u->team, adv = u->sit ? 1 : 0, one = 1;
+    if (hm_sp_set_side(u->sp, &team, &adv)) { u->out += "bestmove (none)\n"; return; }
+    const int target = nodes > 0 ? (int)std::min<size_t>(nodes, (size_t)u->maxNodes) : u->maxNodes;
+    const uint64_t seed = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (hm_sp_begin_search(u->sp, &target, &seed, 0.0f, 0.0f, &one)) { u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
+    int active = 1, which = 0, iters = 0;
+    bool stopped = false;
+    void* heads[5] = {u->io.value, u->io.pi_a, u->io.pi_b, u->io.wdl, u->io.moves_left};
+    while (active > 0 && iters < 200000) {
+        int rc = hm_sp_collect(u->sp, u->io.planes[1 - which], nullptr);
+        if (!rc) rc = u->net ? hm_net_forward(u->net, u->io.planes[which], 8, heads[0], heads[1], heads[2], heads[3], heads[4], nullptr)
+                             : u->fn(u->user, which, 8);
+        if (!rc) rc = hm_sp_process(u->sp, heads[0], heads[1], heads[2], heads[3], heads[4], &active, nullptr);
+        if (rc) { u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
+        which = 1 - which;
+        ++iters;
+        if (!stopped && nodes == 0 && elapsed_ms() >= (double)moveTime) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }
+    }
+    const int E = hm_sp_max_edges(u->sp);
+    std::vector<hm_move> mA(E), mB(E);
+    std::vector<int> visits(E), info(HM_SP_INFO_INTS);
+    std::vector<float> q(E);
+    int count = 0;
+    float rootQ = 0.0f;
+    if (hm_sp_root_stats(u->sp, &count, mA.data(), mB.data(), visits.data(), q.data(), nullptr, &rootQ, info.data(), E)) { u->out += "bestmove (none)\n"; return; }
+    const double ms = elapsed_ms();
+    const int nodesDone = info[1], depth = info[9], best = info[12];
+    if (count <= 0 || best < 0 || best >= count) { u->out += "bestmove (none)\n"; return; }
+    const std::string bestText = "(" + uci_text(mA[best]) + "," + uci_text(mB[best]) + ")";
+    const int nps = ms > 0 ? (int)(nodesDone * 1000.0 / ms) : 0;
+    char line[512];
+    std::snprintf(line, sizeof line, "info depth %d %s nodes %d nps %d hashfull 0 tbhits 0 time %d pv %s\n", depth,
+                  uci_score(info[14], info[15], q[best]).c_str(), nodesDone, nps, (int)ms, bestText.c_str());
+    u->out += line;
+    std::snprintf(line, sizeof line, "info string rejected selection attempts %d (same batch %d, pending evaluation %d)\n", info[3] + info[4], info[3], info[4]);
+    u->out += line;
+    u->out += "bestmove " + bestText + "\n";
+}
+
+static void uci_setoption(hm_uci* u, std::istringstream& is) {   // uci.cc:239-296
+    std::string token, name, value;
+    is >> token;
+    if (token != "name") return;
+    is >> name >> token;
+    if (token != "value") return;
+    is >> value;
+    auto permille = [&](int lo, int hi) { return std::min(std::max(std::atoi(value.c_str()), lo), hi); };
+    bool rebuild = false;
+    if (name == "Hash") u->out += "info string Hash table set to " + value + " MB\n";            // per-search table sized from the node budget here
+    else if (name == "MultiPV") { const int v = std::atoi(value.c_str()); if (v >= 1 && v <= 500) { u->multiPV = v; u->out += "info string MultiPV set to " + std::to_string(v) + "\n"; } }
+    else if (name == "Ponder") { if (value == "true" || value == "false") { u->ponder = value == "true"; u->out += "info string Ponder set to " + value + "\n"; } }
+    else if (name == "DrawContemptPermille") { const int v = permille(0, 1000); u->scfg.draw_contempt = (float)v / 1000.0f; rebuild = true; u->out += "info string DrawContemptPermille set to " + std::to_string(v) + "\n"; }
+    else if (name == "PWCoefficientPermille") { const int v = permille(1, 10000); u->scfg.pw_coefficient = (float)v / 1000.0f; rebuild = true; u->out += "info string PWCoefficientPermille set to " + std::to_string(v) + "\n"; }
+    else if (name == "RootPWCoefficientPermille") { const int v = permille(1, 10000); u->scfg.root_pw_coefficient = (float)v / 1000.0f; rebuild = true; u->out += "info string RootPWCoefficientPermille set to " + std::to_string(v) + "\n"; }
+    else if (name == "PWExponentPermille") { const int v = permille(1, 1000); u->scfg.pw_exponent = (float)v / 1000.0f; rebuild = true; u->out += "info string PWExponentPermille set to " + std::to_string(v) + "\n"; }
+    else if (name == "Transpositions") { if (value == "true" || value == "false") { u->scfg.enable_transpositions = value == "true"; rebuild = true; u->out += "info string Transpositions set to " + value + "\n"; } }
+    else if (name == "Team") { if (value == "white") u->team = HM_WHITE; else if (value == "black") u->team = HM_BLACK; }
+    else if (name == "Mode") { if (value == "sit") u->sit = true; else if (value == "go") u->sit = false; }
+    if (rebuild) {
+        // the search configuration lives in the engine handle: rebuild it and put the game back (its history restarts, as after
+        // a `position` command, which the GUI sends before every `go` anyway)
+        const hm_board keep = u->board;
+        if (uci_rebuild_engine(u) || uci_set_position(u, keep)) u->out += std::string("info string setoption failed: ") + hm_last_error() + "\n";
+    }
+}
+
+extern "C" {
+
+int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* user, int max_nodes, hm_uci** out) {
+    if (!io || !out || (!net && !fn) || max_nodes <= 0) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (!io->planes[0] || !io->planes[1] || !io->value || !io->pi_a || !io->pi_b || !io->wdl || !io->moves_left) return hm_fail(HM_ERR_INVALID, "evaluator buffers missing");
+    hm_uci* u = new hm_uci();
+    u->net = net; u->fn = fn; u->user = user; u->io = *io; u->maxNodes = max_nodes;
+    hm_search_config_default(&u->scfg);
+    if (int rc = uci_rebuild_engine(u)) { delete u; return rc; }
+    if (hipMalloc(&u->d_pos, sizeof(hm_pos)) != hipSuccess || hipMalloc(&u->d_moves, 4 * HM_MAX_MOVES) != hipSuccess || hipMalloc(&u->d_counts, 4) != hipSuccess) {
+        hm_uci_destroy(u);
+        return hm_fail(HM_ERR_NO_DEVICE, "hipMalloc failed");
+    }
+    hm_board b;
+    hm_board_startpos(&b);
+    if (int rc = uci_set_position(u, b)) { hm_uci_destroy(u); return rc; }
+    *out = u;
+    return 0;
+}
+
+// One UCI command line in, the engine's output text out (0-terminated, possibly several lines).  Returns the text length,
+// -(needed size) when `cap` is too small (the command has been executed; call again with an empty line to fetch the text),
+// and HM_UCI_QUIT for `quit`.
+int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
+    if (!u || !line) return hm_fail(HM_ERR_INVALID, "null argument");
+    std::istringstream is(line);
+    std::string token;
+    is >> std::skipws >> token;
+    bool quit = false;
+    if (token == "uci") {   // send_uci_response, uci.cc:298-317
+        u->out += "id name hivemind\nid author aminwoo\n\n"
+                  "option name Hash type spin default 16 min 1 max 33554432\n"
+                  "option name MultiPV type spin default 1 min 1 max 500\n"
+                  "option name Ponder type check default true\n"
+                  "option name DrawContemptPermille type spin default 0 min 0 max 1000\n"
+                  "option name PWCoefficientPermille type spin default 1000 min 1 max 10000\n"
+                  "option name RootPWCoefficientPermille type spin default 4000 min 1 max 10000\n"
+                  "option name PWExponentPermille type spin default 300 min 1 max 1000\n"
+                  "option name Transpositions type check default true\n"
+                  "option name Team type combo default white var white var black\n"
+                  "option name Mode type combo default go var sit var go\n"
+                  "info string HIP engines 1 search workers 1 (one wavefront pipeline per game)\n"
+                  "uciok\n";
+    } else if (token == "isready") u->out += "readyok\n";
+    else if (token == "go") uci_go(u, is);
+    else if (token == "setoption") uci_setoption(u, is);
+    else if (token == "position") uci_position(u, is);
+    else if (token == "ucinewgame") { hm_board b; hm_board_startpos(&b); (void)uci_set_position(u, b); }   // new_game: search state is per `go` here
+    else if (token == "stop" || token == "ponderhit") {}          // searches are synchronous: nothing is running between commands
+    else if (token == "quit") quit = true;
+    if ((int64_t)u->out.size() + 1 > cap || !out) return quit ? HM_UCI_QUIT : -(int64_t)u->out.size() - 1;
+    std::memcpy(out, u->out.c_str(), u->out.size() + 1);
+    const int64_t n = (int64_t)u->out.size();
+    u->out.clear();
+    return quit ? HM_UCI_QUIT : n;
+}
+
+// the current game position (after the last `position` command) for tests and GUIs that mirror the board
+int hm_uci_board(hm_uci* u, hm_board* out) {
+    if (!u || !out) return hm_fail(HM_ERR_INVALID, "null argument");
+    *out = u->board;
+    out->team = (uint8_t)u->team; out->time_adv = u->sit ? 1 : 0;
+    return 0;
+}
+
+int hm_uci_destroy(hm_uci* u) {
+    if (!u) return 0;
+    if (u->sp) hm_sp_destroy(u->sp);
+    if (u->d_pos) (void)hipFree(u->d_pos);
+    if (u->d_moves) (void)hipFree(u->d_moves);
+    if (u->d_counts) (void)hipFree(u->d_counts);
+    delete u;
+    return 0;
+}
+
+}  // extern "C"

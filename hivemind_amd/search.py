@@ -47,6 +47,8 @@ _SIGS = {
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
     "hm_sp_classify": (_i, [_vp, _vp, _vp]),
     "hm_sp_set_pw_profiles": (_i, [_vp, C.c_float, C.c_float, _vp]),
+    "hm_sp_set_side": (_i, [_vp, _vp, _vp]),
+    "hm_sp_stop": (_i, [_vp, _vp, _vp]),
     "hm_sp_profile": (_i, [_vp, _i]),
     "hm_sp_profile_launches": (_i, [_vp, _i]),
     "hm_sp_trace_select": (_i, [_i]),

@@ -185,6 +185,11 @@ int hm_sp_create(int n_games, int max_nodes, const hm_search_config* cfg, hm_sp*
  * (Board::positionHistory grows by one key per push, board.h:95-102); 0 = the default of 1024 keys. */
 int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_search_config* cfg, hm_sp** out);
 int hm_sp_destroy(hm_sp* sp);
+/* Side to act per game slot (team[g] = HM_WHITE / HM_BLACK, time_adv[g] = the team sits with the time advantage), positions and
+ * history untouched: the UCI options Team / Mode (interface/uci.cc:283-296) after a `position ... moves` replay. */
+int hm_sp_set_side(hm_sp* sp, const uint8_t* team, const uint8_t* time_adv);
+/* Ends the searches of the masked slots (all if NULL) at their next collect: Agent::set_is_running(false) — UCI `stop`, movetime. */
+int hm_sp_stop(hm_sp* sp, const uint8_t* mask, void* stream);
 /* Progressive-widening schedule per game slot (TournamentConfig::searchConfigFor, tools/tournament.h:34-41): profiles[g] != 0
  * makes slot g search with the alternate coefficients (root and interior); 0 = the engine's hm_search_config. */
 int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw_coefficient, const uint8_t* profiles);
@@ -210,7 +215,8 @@ int hm_sp_active(hm_sp* sp, int* active);
  * tree nodes visited and edges scanned during selection (traffic accounting), [12] = index of the
  * joint action Agent::run_search returns (get_best_move_idx_with_q_weight, node.h:656-754 with
  * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13] = leaf move-list words written
- * (traffic accounting), [14..15] reserved. */
+ * (traffic accounting), [14] / [15] = solver type (0 unsolved, 1 win, 2 loss, 3 draw — from the child's side) and endInPly of that
+ * action's child node (format_uci_score, agent.cc:48-78). */
 #define HM_SP_INFO_INTS 16
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
@@ -448,6 +454,30 @@ int hm_tournament_statistics(uint64_t contender_wins, uint64_t baseline_wins, ui
                              hm_tournament_result* out);
 /* UCI::move text of a move of this variant (Board::uci_move, environment/board.h:340-350; MOVE_NONE -> "pass"). */
 int hm_move_uci(hm_move move, char* out, int cap);
+
+/* ================================================================== */
+/* UCI front end (interface/uci.cc:82-317, 396-429) over one game slot  */
+/* of the GPU search engine: `position` replays the game on the device, */
+/* `go nodes N` / `go movetime T` searches and prints `info ...` and     */
+/* `bestmove (<moveA>,<moveB>)` with the solver-aware move rule          */
+/* (agent.cc:1031-1049).  Built: uci, isready, ucinewgame, position      */
+/* startpos|fen [moves <1|2><uci>...], go, stop, setoption (Team, Mode,  */
+/* DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,*/
+/* PWExponentPermille, Transpositions; Hash / MultiPV / Ponder accepted), */
+/* quit.  Not built: pondering, tree reuse, multi-PV / PV lines, the      */
+/* `policy` command, movetime heuristics (early stop / extension).        */
+/* ================================================================== */
+typedef struct hm_uci hm_uci;
+#define HM_UCI_QUIT (-1000000)
+/* net: loaded network (hm_net_create / hm_engine_net), or NULL with a callback evaluator `fn` (rows 0..7 of io->planes[which]);
+ * io: caller-owned device buffers for 8 rows (planes[2], five heads); max_nodes: largest node budget of a `go`. */
+int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* user, int max_nodes, hm_uci** out);
+/* One command line in, the engine's output text out (several lines possible).  Returns the text length, -(needed size)
+ * when cap is too small (the command HAS run; call again with "" to fetch the text) and HM_UCI_QUIT for `quit`. */
+int64_t hm_uci_command(hm_uci* uci, const char* line, char* out, int64_t cap);
+/* The current game position (after the last `position`), team / time_adv = the Team / Mode options. */
+int hm_uci_board(hm_uci* uci, hm_board* out);
+int hm_uci_destroy(hm_uci* uci);
 
 #ifdef __cplusplus
 }

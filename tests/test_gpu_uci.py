@@ -1,0 +1,143 @@
+"""UCI front end (hm_uci_*, interface/uci.cc) on the GPU search engine: the command dialect, `position` replay (FEN parsing,
+single-board move lists, history) against the CPU restatement's Board, and `go nodes N` against the CPU restatement's search
+under the shared stand-in network — same solver-aware best move (agent.cc:1031-1049), same node count."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+START = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1"
+
+
+@pytest.fixture(scope="module")
+def hm():
+    import hivemind_amd as hm
+    hm.init(0)
+    return hm
+
+
+class DeviceHashNet:
+    native = False
+
+    def __init__(self, hm):
+        self.hm = hm
+
+    def __call__(self, planes):
+        n = planes.shape[0]
+        f16 = dict(dtype=torch.float16, device=planes.device)
+        out = (torch.empty(n, **f16), torch.empty((n, 4672), **f16), torch.empty((n, 4672), **f16), torch.empty((n, 3), **f16), torch.empty(n, **f16))
+        self.hm.check(self.hm.lib.hm_hash_evaluator(planes.data_ptr(), n, 0, *[t.data_ptr() for t in out], None))
+        return out
+
+
+def _oracle_board(fen=None, moves=()):
+    b = O.Board()
+    if fen:
+        b.set(fen)
+    for tok in moves:
+        bd = int(tok[0]) - 1
+        m = b.find_move(bd, tok[1:])
+        assert m != 0, tok
+        b.push(bd, m)
+    return b
+
+
+def test_uci_handshake_and_options(hm):
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=2000)
+    text, quit_ = u.command("uci")
+    assert text.startswith("id name hivemind\nid author aminwoo\n") and text.rstrip().endswith("uciok") and not quit_
+    for opt in ("Hash", "MultiPV", "Ponder", "DrawContemptPermille", "PWCoefficientPermille", "RootPWCoefficientPermille", "PWExponentPermille",
+                "Transpositions", "Team", "Mode"):
+        assert f"option name {opt} " in text
+    assert u.command("isready") == ("readyok\n", False)
+    assert u.command("setoption name MultiPV value 3")[0] == "info string MultiPV set to 3\n"
+    assert u.command("setoption name DrawContemptPermille value 2500")[0] == "info string DrawContemptPermille set to 1000\n"   # clamped, uci.cc:265
+    assert u.command("setoption name Team value black") == ("", False)
+    assert u.board()["team"][0] == 1
+    assert u.command("stop") == ("", False)
+    assert u.command("quit")[1] is True
+    u.close()
+
+
+@pytest.mark.parametrize("fen,moves", [
+    (None, ["1e2e4", "2d2d4", "1e7e5", "2g8f6", "1g1f3", "1b8c6", "1f1c4", "1f8c5", "1e1g1"]),                     # castling text e1g1
+    ("r1bqkb1r/pppp1ppp/2n2n2/4p3/2B1P3/5N2/PPPP1PPP/RNBQK2R[Pn] w KQkq - 4 4|" + START, ["1P@d3", "2e2e4", "1N@g4"]),   # pockets, drops
+    ("rnbqkbnr/ppp1p1pp/8/3pPp2/8/8/PPPP1PPP/RNBQKBNR w KQkq f6 0 3|rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR/Qq b KQkq - 0 1",
+     ["1e5f6", "2Q@e4"]),                                                                                            # en passant; pocket after the 8th slash
+    ("8/P6k/8/8/8/8/8/K7[] w - - 0 1|" + START, ["1a7a8q", "2e2e4"]),                                                  # promotion text
+])
+def test_position_replay_matches_oracle_board(hm, fen, moves):
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=500)
+    cmd = ("position fen " + fen if fen else "position startpos") + " moves " + " ".join(moves)
+    text, _ = u.command(cmd)
+    assert text == "", text
+    want = _oracle_board(fen, moves).compact(0, False)
+    got = u.board()
+    assert got["pos"].tobytes() == want["pos"].tobytes()                      # both positions, Zobrist keys included
+    assert np.array_equal(got["last_move"], want["last_move"]) and np.array_equal(got["rep_count"], want["rep_count"])
+    # an illegal move is reported and the replay stops there (uci.cc:118-136)
+    text, _ = u.command("position startpos moves 1e2e4 1e2e4")
+    assert "Invalid move 'e2e4' on board 1 at move 2" in text
+    u.close()
+
+
+@pytest.mark.parametrize("team,mode,moves,nodes", [("white", "go", [], 200), ("black", "sit", ["1e2e4", "2d2d4"], 320),
+                                                   ("white", "sit", ["1e2e4", "1e7e5", "2d2d4"], 160)])
+def test_go_nodes_matches_oracle_search(hm, team, mode, moves, nodes):
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=2000)
+    u.command(f"setoption name Team value {team}")
+    u.command(f"setoption name Mode value {mode}")
+    u.command("position startpos" + (" moves " + " ".join(moves) if moves else ""))
+    text, _ = u.command(f"go nodes {nodes}")
+    lines = text.strip().split("\n")
+    assert lines[-1].startswith("bestmove (") and lines[0].startswith("info depth ")
+    b = _oracle_board(None, moves)
+    s = O.Search(1, 1)
+    t, adv = (0 if team == "white" else 1), mode == "sit"
+    assert s.run(b, t, adv, nodes)
+    e = s.edges()
+    best = s.best_move()
+    want = "(" + O.move_uci(e["move_a"][best]) + "," + O.move_uci(e["move_b"][best]) + ")"
+    assert lines[-1] == "bestmove " + want, (lines, want)
+    m = re.match(r"info depth (\d+) score (cp|mate) (-?\d+) nodes (\d+) nps (\d+) hashfull 0 tbhits 0 time (\d+) pv (\(.*\))$", lines[0])
+    assert m and int(m.group(4)) == s.info()["nodes"] and m.group(7) == want, lines[0]
+    if m.group(2) == "cp":
+        import math
+        assert int(m.group(3)) == int(180.0 * math.tan(1.56 * float(e["q"][best])))          # format_uci_score, agent.cc:75
+    u.close()
+
+
+def test_go_without_a_board_on_turn_says_none(hm):
+    """neither of the team's boards is on turn and sitting out is not allowed: Agent::run_search prints `bestmove (none)`
+    (agent.cc:438-450); the CPU restatement refuses the search as well"""
+    moves = ["1e2e4", "2d2d4", "1e7e5"]
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=500)
+    u.command("setoption name Team value black")
+    u.command("setoption name Mode value sit")
+    u.command("position startpos moves " + " ".join(moves))
+    assert u.command("go nodes 100")[0].strip().split("\n")[-1] == "bestmove (none)"
+    assert not O.Search(1, 1).run(_oracle_board(None, moves), 1, True, 100)
+    u.close()
+
+
+def test_go_movetime_returns_a_legal_best_move(hm):
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    u = hm.Uci(N.FusedNet(N.rise_v3_small()), max_nodes=50000)
+    u.command("position startpos moves 1e2e4 2e2e4")
+    text, _ = u.command("go movetime 60")
+    last = text.strip().split("\n")[-1]
+    m = re.match(r"bestmove \((\S+),(\S+)\)$", last)
+    assert m, text
+    b = _oracle_board(None, ["1e2e4", "2e2e4"])
+    for bd, mv in ((0, m.group(1)), (1, m.group(2))):
+        assert mv == "pass" or b.find_move(bd, mv) != 0, (bd, mv)
+    info = [l for l in text.split("\n") if l.startswith("info depth")][0]
+    t = int(re.search(r" time (\d+) ", info).group(1))
+    assert 55 <= t < 400, info                                               # ran to the deadline, then finished the batches in flight
+    u.close()

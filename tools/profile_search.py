@@ -8,7 +8,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "hivemind_amd", "csrc", "libhivemind_amd_prof.so")
 if "--build" in sys.argv:
-    src = [os.path.join(ROOT, "hivemind_amd", "csrc", f) for f in ("hm_kernels.hip", "hm_search.hip", "hm_selfplay.hip", "hm_net.hip", "hm_engine.hip")]
+    src = [os.path.join(ROOT, "hivemind_amd", "csrc", f) for f in ("hm_kernels.hip", "hm_search.hip", "hm_selfplay.hip", "hm_net.hip", "hm_engine.hip", "hm_uci.hip")]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared", "-DHM_SEARCH_PROF",
                            "-I", os.path.join(ROOT, "include"), *src, "-o", PROF])
     print("built", PROF)
