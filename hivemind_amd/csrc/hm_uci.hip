@@ -13,8 +13,8 @@
 // stop, setoption name {Team, Mode, DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,
 // PWExponentPermille, Transpositions} (Hash, MultiPV, Ponder are accepted and reported as the reference does), quit.
 // Not built (documented in DESIGN.md): pondering / ponderhit, tree reuse between moves, multi-PV lines and PV extraction
-// beyond the best move, the `policy` debug command, and the movetime heuristics (early stopping, time extension): a movetime
-// search runs until the deadline.  A search is synchronous: the command returns when `bestmove` has been printed.
+// beyond the best move and the `policy` debug command.  `go movetime` follows the reference's polling loop (early exit on a
+// solved root / forced mate, early stopping on an insurmountable visit lead, time extension).  A search is synchronous: the command returns when `bestmove` has been printed.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -31,6 +31,7 @@
 
 const HostTables& hm_host_tables();
 int hm_fail(int code, const std::string& msg);
+extern "C" int hm_insurmountable_visit_lead(float best_visits, float projected_second_visits, float factor);
 
 namespace {
 
@@ -119,6 +120,65 @@ std::string trim(const std::string& s) {
 }
 
 }  // namespace
+
+// The time-managed part of Agent::run_search's polling loop (agent.cc:561-713) as a pure host object: fed the root's edge
+// statistics every poll, it answers stop / continue and keeps the effective move time (SearchInfo, searchinfo.h:55-63,
+// 129-180).  Constants: search_params.h:204-246.
+struct hm_time_manager {
+    int moveTimeMs = 0;
+    double effectiveMs = 0.0;
+    int extensions = 0;
+    float nps = 0.0f;
+    float lastCheckEval = 0.0f;
+    bool evalInitialized = false;
+    int lastBestChildIdx = -1;
+    std::string log;                  // the `info string ...` lines the reference prints at these decisions
+};
+static bool tm_try_extend(hm_time_manager& t, double elapsedMs, float factor = 1.5f, int maxExtensions = 2) {   // SearchInfo::try_extend_time
+    if (t.extensions >= maxExtensions) return false;
+    const double remaining = t.effectiveMs - elapsedMs;
+    if (remaining <= 0) return false;
+    t.effectiveMs += static_cast<int>(remaining * (factor - 1.0f));
+    t.extensions++;
+    return true;
+}
+// one poll; returns true when the search should stop now
+static bool tm_poll(hm_time_manager& t, double elapsedMs, int nodes, int n, const int* visits, const float* q, int rootType, const int* childType, const int* childEndInPly) {
+    const double elapsedSec = elapsedMs / 1000.0;                                    // SearchInfo::update_nps
+    if (elapsedSec > 0.1) {
+        const float cur = static_cast<float>(nodes / elapsedSec);
+        t.nps = t.nps == 0.0f ? cur : 0.9f * t.nps + 0.1f * cur;
+    }
+    if (n <= 0) return false;
+    int firstMax = 0, secondMax = 0, firstIdx = 0, secondIdx = -1;                   // agent.cc:603-616
+    for (int i = 0; i < n; ++i) {
+        if (visits[i] > firstMax) { secondMax = firstMax; secondIdx = firstIdx; firstMax = visits[i]; firstIdx = i; }
+        else if (visits[i] > secondMax) { secondMax = visits[i]; secondIdx = i; }
+    }
+    const float bestQ = q[firstIdx], secondQ = secondIdx >= 0 ? q[secondIdx] : -1.0f;
+    if (!t.evalInitialized) { t.lastCheckEval = bestQ; t.evalInitialized = true; }
+    // should_exit_early_winning (agent.cc:92-129)
+    if (rootType != 0) { t.log += std::string("info string Early exit: root position is proven ") + (rootType == 1 ? "WIN" : rootType == 2 ? "LOSS" : "DRAW") + "\n"; return true; }
+    if (childType && childType[firstIdx] == 2) { t.log += "info string Early exit: forced mate in " + std::to_string((childEndInPly[firstIdx] + 1) / 2) + " found\n"; return true; }
+    if (t.nps > 0) {                                                                 // early stopping (agent.cc:634-652)
+        const double remaining = t.effectiveMs - elapsedMs;
+        const float projected = static_cast<float>(secondMax) + static_cast<float>(remaining * t.nps / 1000.0);
+        if (hm_insurmountable_visit_lead(static_cast<float>(firstMax), projected, 2.0f) && bestQ >= secondQ) {
+            t.log += "info string Early stopping: saved " + std::to_string(static_cast<int>(std::max(0.0, (double)t.moveTimeMs - elapsedMs))) + "ms\n";
+            return true;
+        }
+    }
+    {                                                                                // time extension (agent.cc:655-678)
+        const float evalDrop = t.lastCheckEval - bestQ;
+        if (evalDrop > 0.05f && tm_try_extend(t, elapsedMs))
+            t.log += "info string Extending search time (eval dropped by " + std::to_string(static_cast<int>(evalDrop * 100)) + " cp)\n";
+        t.lastCheckEval = bestQ;
+        if (t.lastBestChildIdx >= 0 && firstIdx != t.lastBestChildIdx && elapsedMs > t.moveTimeMs * 0.4f && tm_try_extend(t, elapsedMs))
+            t.log += "info string Extending search time (best move changed to " + std::to_string(firstIdx) + ")\n";
+        t.lastBestChildIdx = firstIdx;
+    }
+    return elapsedMs >= t.effectiveMs;
+}
 
 struct hm_uci {
     const hm_net* net = nullptr;
@@ -234,6 +294,12 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
     int active = 1, which = 0, iters = 0;
     bool stopped = false;
     void* heads[5] = {u->io.value, u->io.pi_a, u->io.pi_b, u->io.wdl, u->io.moves_left};
+    hm_time_manager tm;
+    tm.moveTimeMs = moveTime; tm.effectiveMs = moveTime;
+    double lastPoll = 0.0;
+    const int E0 = hm_sp_max_edges(u->sp);
+    std::vector<int> pv(E0), pinfo(HM_SP_INFO_INTS), ptype(E0), pend(E0);
+    std::vector<float> pq(E0);
     while (active > 0 && iters < 200000) {
         int rc = hm_sp_collect(u->sp, u->io.planes[1 - which], nullptr);
         if (!rc) rc = u->net ? hm_net_forward(u->net, u->io.planes[which], 8, heads[0], heads[1], heads[2], heads[3], heads[4], nullptr)
@@ -242,7 +308,26 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
         if (rc) { u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
         which = 1 - which;
         ++iters;
-        if (!stopped && nodes == 0 && elapsed_ms() >= (double)moveTime) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }
+        if (!stopped && nodes == 0 && active > 0) {
+            // the reference polls every 5 ms (agent.cc:562, 577-580): early exit on a solved root / forced mate, early stopping
+            // on an insurmountable visit lead, time extension on a falling evaluation or a late change of the best move
+            const double now = elapsed_ms();
+            bool stop = now >= tm.effectiveMs;
+            if (!stop && now - lastPoll >= 5.0) {
+                lastPoll = now;
+                int count = 0;
+                float rq = 0.0f;
+                if (!hm_sp_root_stats(u->sp, &count, nullptr, nullptr, pv.data(), pq.data(), nullptr, &rq, pinfo.data(), E0)) {
+                    // solver types of the children are not part of the root statistics: the forced-mate exit uses the best
+                    // action's child (info[14..15]), which is the only child the rule looks at
+                    for (int i = 0; i < count; ++i) { ptype[i] = 0; pend[i] = 0; }
+                    if (pinfo[12] >= 0 && pinfo[12] < count) { ptype[pinfo[12]] = pinfo[14]; pend[pinfo[12]] = pinfo[15]; }
+                    stop = tm_poll(tm, now, pinfo[1], count, pv.data(), pq.data(), pinfo[6] > 0 ? pinfo[6] : 0, ptype.data(), pend.data());
+                    u->out += tm.log; tm.log.clear();
+                }
+            }
+            if (stop) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }
+        }
     }
     const int E = hm_sp_max_edges(u->sp);
     std::vector<hm_move> mA(E), mB(E);
@@ -293,6 +378,22 @@ static void uci_setoption(hm_uci* u, std::istringstream& is) {   // uci.cc:239-2
 }
 
 extern "C" {
+
+// SearchParams::has_insurmountable_visit_lead (search_params.h:322-326)
+int hm_insurmountable_visit_lead(float best_visits, float projected_second_visits, float factor) { return projected_second_visits * factor < best_visits ? 1 : 0; }
+
+// the movetime controller alone, for tests: feed polls, read decisions (host-only)
+hm_time_manager* hm_time_manager_create(int move_time_ms) { hm_time_manager* t = new hm_time_manager(); t->moveTimeMs = move_time_ms; t->effectiveMs = move_time_ms; return t; }
+int hm_time_manager_poll(hm_time_manager* t, double elapsed_ms, int nodes, int n, const int* visits, const float* q, int root_type, const int* child_type,
+                         const int* child_end_in_ply, double* effective_ms, char* log, int cap) {
+    if (!t || (n > 0 && (!visits || !q))) return hm_fail(HM_ERR_INVALID, "null argument");
+    const bool stop = tm_poll(*t, elapsed_ms, nodes, n, visits, q, root_type, child_type, child_end_in_ply);
+    if (effective_ms) *effective_ms = t->effectiveMs;
+    if (log && cap > 0) { std::snprintf(log, (size_t)cap, "%s", t->log.c_str()); }
+    t->log.clear();
+    return stop ? 1 : 0;
+}
+void hm_time_manager_destroy(hm_time_manager* t) { delete t; }
 
 int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* user, int max_nodes, hm_uci** out) {
     if (!io || !out || (!net && !fn) || max_nodes <= 0) return hm_fail(HM_ERR_INVALID, "null argument");

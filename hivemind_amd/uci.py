@@ -17,6 +17,10 @@ _SIGS = {
     "hm_uci_command": (C.c_int64, [_vp, C.c_char_p, _vp, C.c_int64]),
     "hm_uci_board": (_i, [_vp, _vp]),
     "hm_uci_destroy": (_i, [_vp]),
+    "hm_insurmountable_visit_lead": (_i, [C.c_float, C.c_float, C.c_float]),
+    "hm_time_manager_create": (_vp, [_i]),
+    "hm_time_manager_poll": (_i, [_vp, C.c_double, _i, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(C.c_double), _vp, _i]),
+    "hm_time_manager_destroy": (None, [_vp]),
 }
 for _n, (_r, _a) in _SIGS.items():
     _f = getattr(lib, _n)

@@ -464,8 +464,9 @@ int hm_move_uci(hm_move move, char* out, int cap);
 /* startpos|fen [moves <1|2><uci>...], go, stop, setoption (Team, Mode,  */
 /* DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,*/
 /* PWExponentPermille, Transpositions; Hash / MultiPV / Ponder accepted), */
-/* quit.  Not built: pondering, tree reuse, multi-PV / PV lines, the      */
-/* `policy` command, movetime heuristics (early stop / extension).        */
+/* quit; `go movetime` with the reference's early exit / early stopping /  */
+/* time extension rules.  Not built: pondering, tree reuse, multi-PV / PV  */
+/* lines, the `policy` command.                                            */
 /* ================================================================== */
 typedef struct hm_uci hm_uci;
 #define HM_UCI_QUIT (-1000000)
@@ -478,6 +479,16 @@ int64_t hm_uci_command(hm_uci* uci, const char* line, char* out, int64_t cap);
 /* The current game position (after the last `position`), team / time_adv = the Team / Mode options. */
 int hm_uci_board(hm_uci* uci, hm_board* out);
 int hm_uci_destroy(hm_uci* uci);
+/* SearchParams::has_insurmountable_visit_lead (search/search_params.h:322-326). */
+int hm_insurmountable_visit_lead(float best_visits, float projected_second_visits, float factor);
+/* The movetime controller of Agent::run_search's polling loop (agent.cc:561-713; SearchInfo, searchinfo.h:129-180) alone, host-only:
+ * one poll = the root's edge visits / Q values, root solver type (0 unsolved, 1 win, 2 loss, 3 draw), the children's solver types and
+ * endInPly; returns 1 = stop now, 0 = go on; *effective_ms = move time after extensions; log = the `info string` lines of the decision. */
+typedef struct hm_time_manager hm_time_manager;
+hm_time_manager* hm_time_manager_create(int move_time_ms);
+int hm_time_manager_poll(hm_time_manager* tm, double elapsed_ms, int nodes, int n, const int* visits, const float* q, int root_type,
+                         const int* child_type, const int* child_end_in_ply, double* effective_ms, char* log, int cap);
+void hm_time_manager_destroy(hm_time_manager* tm);
 
 #ifdef __cplusplus
 }
