@@ -11,7 +11,9 @@ hm.init(0)
 torch.manual_seed(0)
 fused = N.FusedNet(N.rise_v3_small())
 digests = {}
-for games, nodes, conc, seed in ((256, 100, 128, 1), (256, 100, 128, 1), (256, 100, 64, 1), (256, 100, 128, 2), (8, 1600, 8, 5)):
+RUNS = [(256, 100, 128, 1), (256, 100, 128, 1), (256, 100, 64, 1), (256, 100, 128, 2), (8, 1600, 8, 5), (8, 1600, 4, 5)]
+RUNS += [(64, 400, c, 7) for c in (64, 64, 32, 64, 16, 64, 48, 64)]      # the bench configuration, repeated: races in the four-wave traversal would show as differing digests
+for games, nodes, conc, seed in RUNS:
     cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=seed, concurrent_games=conc)
     sp = hm.SelfPlay(cfg, fused)
     t = time.time()
