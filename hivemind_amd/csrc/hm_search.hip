@@ -1714,7 +1714,6 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         u32* flA = L.lists[2];
         u32* flB = L.lists[3];
         u32* ord = L.lists[4];           // low 16: A order, high 16: B order (stable_partition by gives_check)
-        u32* hits = L.lists[5];
         int nA = 0, nB = 0;
         if (aOn) nA = gen_legal_wave(rt.att, p.jb.bd[0], la);
         if (bOn) nB = gen_legal_wave(rt.att, p.jb.bd[1], lb);
@@ -1754,7 +1753,6 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
             const bool vA = (int)nb[0].stm == victim, vB = (int)nb[1].stm == (victim ^ 1);
             return (vA && !has_legal_move(rt.att, nb[0])) || (vB && !has_legal_move(rt.att, nb[1]));
         };
-        u32* hitCount = reinterpret_cast<u32*>(&L.unavail[0]);
         bool found = false;
         u32 fa = 0, fb = 0;
         // phases 1/2: a move on one board, pass on the other; phase 3: a move on both boards
@@ -1762,8 +1760,6 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
             const bool on = phase == 0 ? aOn : phase == 1 ? bOn : (aOn && bOn);
             if (!on) continue;
             const int total = phase == 0 ? nA : phase == 1 ? nB : nA * nB;
-            if (lane == 0) *hitCount = 0;
-            __builtin_amdgcn_wave_barrier();
             // Two passes per window of 1024 candidates: the cheap admission test (gives check / a board already in check, sit
             // rules) first, its survivors compacted, then the expensive joint make + "victim has a board without a legal move"
             // on densely packed lanes — few candidates pass the first test, and a wave pays for its slowest lane.
@@ -1780,48 +1776,43 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
                 const int i = (int)(ord[t / nB] & 0xffffu), j = (int)(ord[t % nB] >> 16);
                 return aChk || bChk || (flA[i] & 1) || (flB[j] & 1);
             };
-            for (int w0 = 0; w0 < total; w0 += 1024) {
+            for (int w0 = 0; w0 < total && !found; w0 += 1024) {
                 int nc = 0;
                 for (int t0 = w0; t0 < min(total, w0 + 1024); t0 += 64) {
                     const int t = t0 + lane;
                     const bool ok = t < total && admit(t);
                     const u64 m = __ballot(ok);
-                    if (ok) cand[nc + __popcll(m & ((1ULL << lane) - 1ULL))] = (u32)t;
+                    if (ok) cand[nc + __popcll(m & ((1ULL << lane) - 1ULL))] = (u32)t;      // ascending in t
                     nc += __popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
-                for (int c = lane; c < nc; c += 64) {
-                    const int t = (int)cand[c];
-                    u32 mA = 0, mB = 0;
+                auto moves_of = [&](int t, u32& mA, u32& mB) {
+                    mA = 0; mB = 0;
                     if (phase == 0) mA = la[ord[t] & 0xffffu];
                     else if (phase == 1) mB = lb[ord[t] >> 16];
                     else { mA = la[ord[t / nB] & 0xffffu]; mB = lb[ord[t % nB] >> 16]; }
+                };
+                for (int c = lane; c < nc; c += 64) {
+                    const int t = (int)cand[c];
+                    u32 mA, mB;
+                    moves_of(t, mA, mB);
                     P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
                     make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
-                    if (no_move_board(nb)) { const u32 slot = atomicAdd(hitCount, 1u); if (slot < HM_MAX_MOVES) hits[slot] = (u32)t; else atomicOr(&gm.overflow, 32); }   // candidate list truncated
+                    if (no_move_board(nb)) cand[c] = (u32)t | 0x80000000u;                 // survivor, marked in place: no list to overflow
+                }
+                __builtin_amdgcn_wave_barrier();
+                // verify this window's survivors in candidate order (the list is ascending) with the full rule
+                for (int c = 0; c < nc && !found; ++c) {
+                    const u32 v = cand[c];
+                    if (!(v >> 31)) continue;
+                    u32 mA, mB;
+                    moves_of((int)(v & 0x7fffffffu), mA, mB);
+                    P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
+                    make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
+                    if (is_checkmate(rt, nb, victim, !adv, scratch)) { found = true; fa = mA; fb = mB; }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
-            int nh = (int)*hitCount;
-            if (nh > HM_MAX_MOVES) nh = HM_MAX_MOVES;
-            // verify survivors in candidate order
-            u32 last = 0;
-            bool first = true;
-            for (int r = 0; r < nh && !found; ++r) {
-                u32 best = 0xffffffffu;
-                for (int q = 0; q < nh; ++q) { const u32 v = hits[q]; if ((first || v > last) && v < best) best = v; }
-                if (best == 0xffffffffu) break;
-                last = best; first = false;
-                u32 mA = 0, mB = 0;
-                if (phase == 0) mA = la[ord[best] & 0xffffu];
-                else if (phase == 1) mB = lb[ord[best] >> 16];
-                else { mA = la[ord[best / nB] & 0xffffu]; mB = lb[ord[best % nB] >> 16]; }
-                P nb[2] = {p.jb.bd[0], p.jb.bd[1]};
-                make_joint(rt.att, rt.zob, nb[0], nb[1], mA, mB);
-                if (is_checkmate(rt, nb, victim, !adv, scratch)) { found = true; fa = mA; fb = mB; }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         if (found) {   // agent.cc:458-499: trivial proven tree
             const int root = node_alloc(s, team, 0);

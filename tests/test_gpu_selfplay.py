@@ -158,3 +158,15 @@ def test_selfplay_full_network_configs3(hm, tmp_path):
     del Callback.wh
     _, rec3, cnt3 = _run(hm, cb, **kw)
     assert cnt3 == cnt and rec3.tobytes() == rec.tobytes()
+
+
+def test_selfplay_root_scan_with_many_surviving_candidates(hm):
+    """Regression (round 2): in this run a root position leaves the victim a board without legal moves after more than 512 joint
+    candidates; the root mate scan used to collect them in a 512-entry list and report HM_ERR_OVERFLOW.  Survivors are now
+    marked in place in the (windowed) candidate list and verified in order, so the run completes."""
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    sp = hm.SelfPlay(hm.default_selfplay_config(games=256, nodes=100, seed=2, concurrent_games=128), N.FusedNet(N.rise_v3_small()))
+    res = sp.run()
+    sp.close()
+    assert res.games == 256 and res.samples > 256 * 20
