@@ -9,22 +9,25 @@
 //   TranspositionTable (per search)          search/transposition_table.h:83-103
 //
 // MI355X-first design (not a port of the threaded CPU tree):
-//   * one wavefront owns one game: its tree lives in HBM pools private to the game (node pool,
-//     a bump arena for per-node edge arrays / candidate frontiers, an open-addressing TT), so
-//     there are no locks, no atomics and no shared_ptr: the reference's mutex / CAS protocols
-//     (virtual loss, evaluation reservations) become plain fields updated in program order.
-//   * all games advance in lockstep: collect (select+expand, virtual loss, terminal
-//     classification, leaf planes) -> one batched network call for every game's leaves ->
-//     process (movegen, masked softmax, sort, frontier seed, value shaping, backup, solver).
-//     The reference's double-buffered lookahead of one SearchThread (B=8) is reproduced per
+//   * one workgroup owns one game: its tree lives in HBM pools private to the game (node pool, a bump arena for per-node
+//     edge arrays / candidate frontiers / cached joint positions, an open-addressing TT), so there are no locks and no
+//     shared_ptr: the reference's mutex / CAS protocols (virtual loss, evaluation reservations) become plain fields
+//     updated in program order by the one wave that walks the tree.
+//   * all games advance in lockstep: collect (select+expand, virtual loss, terminal classification, leaf planes, leaf move
+//     lists) -> one batched network call for every game's leaves -> process (masked softmax, sort, frontier seed, value
+//     shaping, backup, solver).  The reference's double-buffered lookahead of one SearchThread (B=8) is reproduced per
 //     game, so per-game results equal the single-thread reference schedule.
-//   * PUCT child selection is lane-parallel (one edge per lane, wave arg-max with lowest-index
-//     tie break); repetition scans, policy gathers, the prior sort (rank sort) and the plane
-//     writer are lane-parallel too; the sequential tree logic runs wave-uniform.
-//   * libm-sensitive pieces are pinned: exp is a fixed IEEE sequence (hm_expf), cpuct(N) and the
-//     progressive-widening schedule come from host-built tables (std::log / std::pow, the
-//     reference's own expressions), Dirichlet gamma draws are made on the host with
-//     std::gamma_distribution<float> on std::mt19937_64 exactly as node.h:286-315.
+//   * k_collect is a four-wave pipeline per game (one wave per SIMD, the whole register file each; the node pool mirrored
+//     in LDS for the launch): the traversal wave only selects; a classifier wave runs the terminal test and writes the
+//     context record; a plane-writer wave encodes the leaf planes; a generator wave refills candidate frontiers and
+//     generates move lists.  Guards (svc_wait / gen_wait) keep the sequential semantics: the traversal never reads state
+//     a helper still owns, helpers serve their requests in order.
+//   * k_process gives every leaf of the batch its own wave (expansion) beside one wave doing the ordered backups.
+//   * PUCT child selection is lane-parallel (one edge per lane, wave arg-max by DPP row reductions with lowest-index tie
+//     break); repetition scans, policy gathers, the prior sort (rank sort) and the plane writer are lane-parallel too.
+//   * libm-sensitive pieces are pinned: exp is a fixed IEEE sequence (hm_expf), cpuct(N) and the progressive-widening
+//     schedule come from host-built tables (std::log / std::pow, the reference's own expressions), Dirichlet gamma draws
+//     are made on the host with std::gamma_distribution<float> on std::mt19937_64 exactly as node.h:286-315.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1392,7 +1395,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
 }
 
 // =======================================================================================
-// kernels (one wave / block of 64 threads per game)
+// kernels (one workgroup per game)
 // =======================================================================================
 // One lockstep iteration, collect side.  Only the NEXT plane tensor is written, so this is
 // independent of the network launch that reads CUR and the two overlap on separate streams

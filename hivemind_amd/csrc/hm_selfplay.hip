@@ -12,7 +12,11 @@
 //   * every game draws from its own std::mt19937_64 seeded mix_seed(runId, gameIndex) (the reference
 //     threads one engine through its sequential game loop), so results do not depend on how games
 //     are spread over slots, ranks or GPUs;  games are striped gameIndex % world == rank.
-//   * PGN text is not produced (not consumed by training).
+//   * PGN text is not produced by self-play (not consumed by training).
+//
+// The same lockstep core drives run_tournament (tools/tournament.cc:328-465, hm_tournament_* at the end of this file): paired games
+// between two networks, each search evaluated by the network of the team to move (two forwards per iteration over disjoint row
+// sets), summary.json / games.pgn and the result statistics.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
