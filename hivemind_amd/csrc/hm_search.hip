@@ -2283,7 +2283,15 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     p.nodeCap = 3 * (max_nodes + 2 * BATCH) + 64;
     p.histGame = std::max(HIST_GAME_MIN, max_game_plies + 8);        // one key per push on a board, at most one push per macro-ply
     p.histCap = p.histGame + MAX_TRAJ + 8;
-    p.ldsNodes = ((size_t)p.nodeCap * sizeof(Node) <= 118 * 1024 && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+    {
+        // the node mirror shares the CU's 160 KB of LDS with k_collect's static LDS (tables, wave scratch, request slots)
+        hipFuncAttributes fa;
+        size_t staticLds = 48 * 1024;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_collect)) == hipSuccess) staticLds = fa.sharedSizeBytes;
+        else (void)hipGetLastError();
+        const size_t room = staticLds < 160 * 1024 ? 160 * 1024 - staticLds : 0;
+        p.ldsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+    }
     int tt = 64;
     while (tt < 4 * p.nodeCap) tt <<= 1;
     p.ttCap = tt;

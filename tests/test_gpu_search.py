@@ -148,3 +148,24 @@ def test_search_with_non_finite_logits_matches_oracle(hm):
         assert n == len(e["visits"]) and np.array_equal(st["visits"][g, :n], e["visits"]), (g, st["visits"][g, :n], e["visits"])
         assert np.array_equal(st["prior"][g, :n], e["prior"]) and np.array_equal(st["q"][g, :n], e["q"]), g
     eng.close()
+
+
+@pytest.mark.parametrize("nodes", [560, 575, 600])
+def test_search_at_the_lds_mirror_boundary(hm, nodes):
+    """node pools just below / above what fits beside k_collect's static LDS (the mirror is switched off above): the search
+    runs and matches the oracle on both sides of the boundary"""
+    roots = _roots(4, 5)
+    eng = hm.SearchEngine(4, nodes)
+    eng.set_games(roots)
+    eng.begin_search(nodes)
+    eng.run(_hash_eval_gpu)
+    st = eng.root_stats()
+    for g in range(4):
+        b = O.Board()
+        b.from_compact(roots[g:g + 1])
+        s = O.Search(1, 1)
+        if not s.run(b, int(roots["team"][g]), bool(roots["time_adv"][g]), nodes):
+            continue
+        e = s.edges()
+        n = st["counts"][g]
+        assert st["info"][g][8] == 0 and n == len(e["visits"]) and np.array_equal(st["visits"][g, :n], e["visits"]), g
