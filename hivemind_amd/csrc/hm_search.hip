@@ -244,7 +244,11 @@ struct G {               // per-wave view of one game's pools
     const int* genAckSeq;
     GenQ* gq;
     int nv, es;                      // nodes visited / edges scanned by this launch's descents (flushed to Game once)
+    u32* dirty;                      // k_collect with the LDS node mirror: one bit per node the launch may have modified (nullptr otherwise)
 };
+// every node that enters a search path (and every first-reached child before canonicalisation) is marked: those, plus the
+// nodes allocated by this launch, are the only ones the launch can have modified, and the only ones written back to HBM
+__device__ __forceinline__ void mark_dirty(const G& s, int id) { if (s.dirty) s.dirty[id >> 5] |= 1u << (id & 31); }
 // blocks until the classifier wave has settled the outstanding leaf's terminal test (its writes to the leaf's Node are visible after)
 __device__ __forceinline__ void svc_wait(G& s) {
     if (s.inflight < 0) return;
@@ -766,6 +770,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
     int cur = s.g->root;
     bool reserved = false;
     traj[0] = TrajEnt{cur, -1, 0, 0};
+    mark_dirty(s, cur);
     p.len = 1;
     p.posNode = -1;
     while (true) {
@@ -840,6 +845,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
         }
         // Board::make_moves + canonicalize_child, only for a child that has never been reached (no position, hence no hash)
         int cr;
+        mark_dirty(s, next);                                   // also when canonicalisation replaces it below (hash, reservation, position)
         if (s.nodes[next].posOff == 0) {
             if (!position_child(s, rt, p, cur, next, ma, mb)) return -1;
             int pend = -1;
@@ -851,6 +857,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             cr = (s.nodes[next].flags & F_EXPANDED) ? 1 : 0;  // canonicalize_child's early outs: hash already set
         }
         traj[p.len - 1].childIdx = childIdx;
+        mark_dirty(s, next);
         traj[p.len] = TrajEnt{next, -1, ma, mb};
         p.len++;
         if (widened) {
@@ -975,7 +982,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.prm = &prm; s.pl = &pl;
     s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
     s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.ackSeq = nullptr; s.typeSeq = nullptr;
-    s.genInflight = -1; s.genReqSeq = 0; s.genAckSeq = nullptr; s.gq = nullptr; s.nv = 0; s.es = 0;
+    s.genInflight = -1; s.genReqSeq = 0; s.genAckSeq = nullptr; s.gq = nullptr; s.nv = 0; s.es = 0; s.dirty = nullptr;
     return s;
 }
 
@@ -1526,6 +1533,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     constexpr int TABN = 512;                                      // visits beyond this read the tables in HBM
     __shared__ float s_cpuct[TABN];
     __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
+    __shared__ u32 s_dirty[64];                                    // 2048 node bits: more than the largest pool the mirror admits
     static_assert(sizeof(Game) % 4 == 0 && sizeof(Node) == 64, "LDS mirrors are copied in 4 / 16 byte words");
     PROF_INIT();
     PROF_T(ta);
@@ -1544,8 +1552,10 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
     }
     if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
+    if (threadIdx.x < 64) s_dirty[threadIdx.x] = 0;
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
+    const int startCount = s_game.nodeCount;                       // nodes with a higher id are created by this launch
     const bool mirror = prm.ldsNodes != 0 && searching;
     if (mirror) {
         const int words = s_game.nodeCount * 4;                    // uint4 words
@@ -1553,6 +1563,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         uint4* dst = reinterpret_cast<uint4*>(s_nodes);
         for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
         s.nodes = reinterpret_cast<Node*>(s_nodes);
+        s.dirty = s_dirty;
         __syncthreads();
     }
     s.g = &s_game;
@@ -1650,7 +1661,10 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
             const int words = s_game.nodeCount * 4;
             const uint4* src = reinterpret_cast<const uint4*>(s_nodes);
             uint4* dst = reinterpret_cast<uint4*>(gNodes);
-            for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
+            for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) {
+                const int id = i >> 2;                             // only what this launch touched or created goes back to HBM
+                if (id >= startCount || ((s_dirty[id >> 5] >> (id & 31)) & 1u)) dst[i] = src[i];
+            }
         }
         __syncthreads();
         for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
