@@ -139,5 +139,5 @@ def test_go_movetime_returns_a_legal_best_move(hm):
         assert mv == "pass" or b.find_move(bd, mv) != 0, (bd, mv)
     info = [l for l in text.split("\n") if l.startswith("info depth")][0]
     t = int(re.search(r" time (\d+) ", info).group(1))
-    assert 55 <= t < 400, info                                               # ran to the deadline, then finished the batches in flight
+    assert 55 <= t < 1500, info                                              # ran to the deadline, then finished the batches in flight
     u.close()
