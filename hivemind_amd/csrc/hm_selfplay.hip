@@ -134,6 +134,7 @@ struct hm_selfplay {
     // so the dependent launches and cross-stream waits of the inner loop cost graph edges instead of host round trips
     hipGraphExec_t stepGraph = nullptr;
     hipEvent_t gFork = nullptr, gJoin = nullptr;
+    hipEvent_t gCollected[2] = {nullptr, nullptr};
     int graphState = 0;                            // 0 not tried, 1 ready, -1 unavailable (eager loop)
     int32_t* d_rows[2] = {nullptr, nullptr};   // per game slot: plane rows written into planes[k] (ragged evaluator batch)
     // second network (tournaments: contender = io.net, baseline = net2): every slot's search is evaluated by the network of
@@ -251,13 +252,21 @@ constexpr int GRAPH_ITERS = 8;                   // even: the plane / head doubl
 
 // one native lockstep iteration enqueued on (sT, sN): collect(next) on the tree stream beside forward(cur) on the network
 // stream, then process(cur) on the tree stream.  `fork`/`join` are ordering-only events.
-static int enqueue_iteration(hm_selfplay* s, int which, int parity, hipEvent_t fork, hipEvent_t join, bool allRows) {
+static int enqueue_iteration(hm_selfplay* s, int which, int parity, hipEvent_t fork, hipEvent_t join, bool allRows,
+                             hipEvent_t collectedPrev = nullptr, hipEvent_t collectedThis = nullptr) {
     void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
                       {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
     void** h = hv[parity];
-    (void)hipEventRecord(fork, s->sT);             // forward(i) runs behind process(i-1), beside collect(i)
-    (void)hipStreamWaitEvent(s->sN, fork, 0);
+    if (collectedPrev) {
+        // early forward: forward(i) only needs the planes collect(i-1) wrote, so it may start beside process(i-1) (used with the
+        // tree and network streams pinned to disjoint CU sets; process(i-2), the last reader of this head set, precedes collect(i-1))
+        (void)hipStreamWaitEvent(s->sN, collectedPrev, 0);
+    } else {
+        (void)hipEventRecord(fork, s->sT);         // forward(i) runs behind process(i-1), beside collect(i)
+        (void)hipStreamWaitEvent(s->sN, fork, 0);
+    }
     if (int rc = collect_rows(s, 1 - which)) return rc;
+    if (collectedThis) (void)hipEventRecord(collectedThis, s->sT);
     if (int rc = forward_rows(s, which, h, allRows)) return rc;
     (void)hipEventRecord(join, s->sN);
     (void)hipStreamWaitEvent(s->sT, join, 0);
@@ -271,7 +280,12 @@ static void build_step_graph(hm_selfplay* s, bool allRows) {
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(s->sT, hipStreamCaptureModeThreadLocal) != hipSuccess) return;
     int rc = 0;
-    for (int k = 0; k < GRAPH_ITERS && !rc; ++k) rc = enqueue_iteration(s, k & 1, k & 1, s->gFork, s->gJoin, allRows);
+    const bool early = std::getenv("HM_SELFPLAY_EARLY_FORWARD") != nullptr;
+    if (early && (!s->gCollected[0] && (hipEventCreateWithFlags(&s->gCollected[0], hipEventDisableTiming) != hipSuccess
+                                        || hipEventCreateWithFlags(&s->gCollected[1], hipEventDisableTiming) != hipSuccess))) { (void)hipStreamEndCapture(s->sT, &graph); return; }
+    for (int k = 0; k < GRAPH_ITERS && !rc; ++k)
+        rc = early ? enqueue_iteration(s, k & 1, k & 1, s->gFork, s->gJoin, allRows, k > 0 ? s->gCollected[(k - 1) & 1] : nullptr, s->gCollected[k & 1])
+                   : enqueue_iteration(s, k & 1, k & 1, s->gFork, s->gJoin, allRows);
     const hipError_t e = hipStreamEndCapture(s->sT, &graph);
     if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return; }
     if (hipGraphInstantiate(&s->stepGraph, graph, nullptr, nullptr, 0) == hipSuccess) s->graphState = 1;
@@ -467,6 +481,7 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->stepGraph) (void)hipGraphExecDestroy(s->stepGraph);
     if (s->gFork) (void)hipEventDestroy(s->gFork);
     if (s->gJoin) (void)hipEventDestroy(s->gJoin);
+    for (hipEvent_t e : s->gCollected) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->evs) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->sync) if (e) (void)hipEventDestroy(e);
     delete s;
