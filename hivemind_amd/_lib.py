@@ -58,6 +58,7 @@ _SIGS = {
     "hm_net_destroy": (_i, [_vp]),
     "hm_net_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hm_net_forward_groups": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hm_net_forward_groups_timed": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hm_net_profile": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hm_net_save_file": (_i, [C.c_char_p, _vp, _sz, _vp, _sz, _vp, _sz]),
     "hm_engine_create": (_i, [_i, _i, C.POINTER(_vp)]),

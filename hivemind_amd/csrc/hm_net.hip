@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, OCC) void rise_forward_kernel(const NetDesc* _
                                                            h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
                                                            h16* __restrict__ wdl, h16* __restrict__ ml,
                                                            const int* __restrict__ groupRows, int group,
-                                                           unsigned long long* __restrict__ dbg) {
+                                                           unsigned long long* __restrict__ dbg, unsigned long long* __restrict__ clk) {
+    if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // leg clock: (start, end) pair
     // diagnostic stamps (dbg != nullptr only from hm_net_profile): cycle counter at phase boundaries of block 0
     int dbgN = 0;
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(256, OCC) void rise_forward_kernel(const NetDesc* _
         __syncthreads();
         HM_STAMP();   // projection done
     }
+    if (clk && threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #undef HM_STAMP
 }
 
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                                                               h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
                                                               h16* __restrict__ wdl, h16* __restrict__ ml,
                                                               const int* __restrict__ groupRows, int group,
-                                                              unsigned long long* __restrict__ dbg) {
+                                                              unsigned long long* __restrict__ dbg, unsigned long long* __restrict__ clk) {
+    if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // leg clock: (start, end) pair
     int dbgN = 0;
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -827,6 +830,7 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
         __syncthreads();
         HM_STAMP();
     }
+    if (clk && threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #undef HM_STAMP
 }
 
@@ -850,23 +854,23 @@ struct hm_net {
 
 template <typename K>
 static hipError_t launch_forward(K kern, const hm_net* net, int grid, hipStream_t st, const void* d_planes, int n, void* d_value, void* d_pi_a,
-                                 void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg) {
+                                 void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg, unsigned long long* d_clk) {
     using namespace hmn;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), net->lds, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),
                        static_cast<const h16*>(d_planes), n, (int)net->stage, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
                        static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
-                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
+                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg, d_clk);
     return hipGetLastError();
 }
 // applies `f` to the kernel instantiation this network runs on
 template <typename K>
 static hipError_t launch_narrow(K kern, const hm_net* net, int grid, hipStream_t st, const void* d_planes, int n, void* d_value, void* d_pi_a,
-                                void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg) {
+                                void* d_pi_b, void* d_wdl, void* d_moves_left, const int32_t* d_group_rows, int group, unsigned long long* d_dbg, unsigned long long* d_clk) {
     using namespace hmn;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), net->ldsNarrow, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),
                        static_cast<const h16*>(d_planes), n, net->copMax, net->uHalfs, static_cast<h16*>(d_value), static_cast<h16*>(d_pi_a),
                        static_cast<h16*>(d_pi_b), static_cast<h16*>(d_wdl), static_cast<h16*>(d_moves_left),
-                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg);
+                       reinterpret_cast<const int*>(d_group_rows), group, d_dbg, d_clk);
     return hipGetLastError();
 }
 template <typename F>
@@ -969,7 +973,7 @@ int hm_net_destroy(hm_net* net) {
 }
 
 static int net_forward_impl(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group, void* d_value, void* d_pi_a,
-                            void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, unsigned long long* d_dbg) {
+                            void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, unsigned long long* d_dbg, unsigned long long* d_clk = nullptr) {
     if (!net || !d_planes || !d_value || !d_pi_a || !d_pi_b || !d_wdl || !d_moves_left) return hm_fail(HM_ERR_INVALID, "null argument");
     if (n <= 0) return 0;
     if (d_group_rows && group <= 0) return hm_fail(HM_ERR_INVALID, "group size must be positive");
@@ -977,10 +981,10 @@ static int net_forward_impl(const hm_net* net, const void* d_planes, int n, cons
     const bool wide = n <= net->wideRows;           // small batches: one workgroup per CU, full register file
     const hipError_t e = net->narrow
         ? with_narrow(net, [&](auto kern) {
-              return launch_narrow(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
+              return launch_narrow(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg, d_clk);
           })
         : with_kernel(net, wide, [&](auto kern) {
-              return launch_forward(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg);
+              return launch_forward(kern, net, grid, static_cast<hipStream_t>(stream), d_planes, n, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, d_group_rows, group, d_dbg, d_clk);
           });
     if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_forward_kernel: ") + hipGetErrorString(e));
     return 0;
@@ -996,6 +1000,13 @@ int hm_net_forward(const hm_net* net, const void* d_planes, int n,
 int hm_net_forward_groups(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
                           void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream) {
     return net_forward_impl(net, d_planes, n, d_group_rows, group, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr);
+}
+// As hm_net_forward_groups; additionally the launch min-/max-es its start / end (constant 100 MHz device clock) into
+// d_interval[0] / d_interval[1] — the forward's slot of the search engine's leg clock (hm_sp_leg_clock_net).
+int hm_net_forward_groups_timed(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
+                                void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream, uint64_t* d_interval) {
+    return net_forward_impl(net, d_planes, n, d_group_rows, group, d_value, d_pi_a, d_pi_b, d_wdl, d_moves_left, stream, nullptr,
+                            reinterpret_cast<unsigned long long*>(d_interval));
 }
 // diagnostic build of the same launch: d_stamps[256] receives s_memtime at the phase boundaries of workgroup 0
 int hm_net_profile(const hm_net* net, const void* d_planes, int n,

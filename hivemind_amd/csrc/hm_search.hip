@@ -140,7 +140,14 @@ struct Params {          // device-visible configuration + pool geometry
     float qVetoDelta, qValueWeight;      // SearchParams::Q_VETO_DELTA / Q_VALUE_WEIGHT (search_params.h)
 };
 
+// Device-side clock of the three legs of a lockstep iteration (constant 100 MHz counter, s_memrealtime): every workgroup of a
+// kernel min-/max-es its start / end into the leg's interval, the next kernel in stream order folds the finished interval into a
+// running sum.  Gives the exact average launch duration of k_collect / the forward / k_process over ALL launches (graph-replayed
+// ones included), the figure a rocprofv3 kernel trace reports.
+struct LegClock { u64 cStart, cEnd, nStart, nEnd, pStart, pEnd; u64 sumC, sumN, sumP; u64 cntC, cntN, cntP; };
+
 struct Pools {
+    LegClock* clk;
     Game* games;
     Node* nodes;          // [nGames][nodeCap]
     u64* arena;           // [nGames][arenaCap]
@@ -1526,6 +1533,15 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
 // Searches whose pool does not fit (prm.ldsNodes == 0) walk the pool in place.
 __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
+    if (threadIdx.x == 0) {
+        LegClock* ck = pl.clk;
+        if (blockIdx.x == 0) {                                     // the previous k_process has finished: fold its interval
+            const u64 pe = ck->pEnd, ps = ck->pStart;
+            if (pe) { ck->sumP += pe - ps; ck->cntP++; }
+            ck->pStart = ~0ULL; ck->pEnd = 0;
+        }
+        atomicMin(&ck->cStart, (u64)__builtin_amdgcn_s_memrealtime());
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
@@ -1670,6 +1686,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
     }
     PROF_ADD(26, twb);
+    if (threadIdx.x == 0) atomicMax(&pl.clk->cEnd, (u64)__builtin_amdgcn_s_memrealtime());
     PROF_FLUSH();
 }
 
@@ -1677,10 +1694,21 @@ __global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params p
     __shared__ RulesTab s_rt;
     __shared__ ExpLds s_exp[BATCH];
     PROF_INIT();
+    if (threadIdx.x == 0) {
+        LegClock* ck = pl.clk;
+        if (blockIdx.x == 0) {                                     // k_collect and the forward(s) of this iteration have finished
+            const u64 ce = ck->cEnd, cs = ck->cStart, ne = ck->nEnd, ns = ck->nStart;
+            if (ce) { ck->sumC += ce - cs; ck->cntC++; }
+            if (ne) { ck->sumN += ne - ns; ck->cntN++; }
+            ck->cStart = ~0ULL; ck->cEnd = 0; ck->nStart = ~0ULL; ck->nEnd = 0;
+        }
+        atomicMin(&ck->pStart, (u64)__builtin_amdgcn_s_memrealtime());
+    }
     stage_table(&s_rt, pl.rules);
     __syncthreads();
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
+    if (threadIdx.x == 0) atomicMax(&pl.clk->pEnd, (u64)__builtin_amdgcn_s_memrealtime());
 #ifdef HM_SEARCH_PROF
     if (blockIdx.x == 0 && threadIdx.x == 0) g_colLaunch++;
 #endif
@@ -2321,6 +2349,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     Pools& pl = sp->pl;
     const size_t G_ = (size_t)n_games;
     int rc = 0;
+    rc |= dalloc(sp, &pl.clk, 1);
     rc |= dalloc(sp, &pl.games, G_);
     rc |= dalloc(sp, &pl.nodes, G_ * p.nodeCap);
     rc |= dalloc(sp, &pl.arena, G_ * p.arenaCap);
@@ -2395,6 +2424,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     rc |= dalloc(sp, &sp->raw.caps, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.counts, G_ * 2); rc |= dalloc(sp, &sp->raw.onTurn, G_ * 2);
     if (rc) { hm_sp_destroy(sp); return rc; }
     sp->h_rootHash.resize(2 * G_);
+    if (int rc2 = hm_sp_leg_times(sp, nullptr, nullptr, 1)) { hm_sp_destroy(sp); return rc2; }
     *out = sp;
     return 0;
 }
@@ -2423,6 +2453,28 @@ int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
 }
+
+// Leg clock (LegClock above): total device time in ms and launch counts of k_collect / forward / k_process since the last reset.
+// The forward takes part when it is launched with the clock's interval pointer (hm_sp_leg_clock_net + hm_net_forward_groups_timed).
+int hm_sp_leg_times(hm_sp* sp, double* ms3, uint64_t* counts3, int reset) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    LegClock c;
+    HIPCHK(hipMemcpy(&c, sp->pl.clk, sizeof c, hipMemcpyDeviceToHost));
+    if (c.cEnd) { c.sumC += c.cEnd - c.cStart; c.cntC++; }          // intervals no later kernel has folded yet
+    if (c.nEnd) { c.sumN += c.nEnd - c.nStart; c.cntN++; }
+    if (c.pEnd) { c.sumP += c.pEnd - c.pStart; c.cntP++; }
+    if (ms3) { ms3[0] = (double)c.sumC * 1e-5; ms3[1] = (double)c.sumN * 1e-5; ms3[2] = (double)c.sumP * 1e-5; }   // 100 MHz ticks
+    if (counts3) { counts3[0] = c.cntC; counts3[1] = c.cntN; counts3[2] = c.cntP; }
+    if (reset) {
+        LegClock z;
+        std::memset(&z, 0, sizeof z);
+        z.cStart = z.nStart = z.pStart = ~0ULL;
+        HIPCHK(hipMemcpy(sp->pl.clk, &z, sizeof z, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+// device pointer to the forward's (start, end) pair of the leg clock
+uint64_t* hm_sp_leg_clock_net(hm_sp* sp) { return sp ? reinterpret_cast<uint64_t*>(&sp->pl.clk->nStart) : nullptr; }
 
 int hm_sp_destroy(hm_sp* sp) {
     if (!sp) return 0;

@@ -159,10 +159,11 @@ static int collect_rows(hm_selfplay* s, int next) {
 }
 // forward(cur) on the network stream: one launch, or one per network over its slots' rows
 static int forward_rows(hm_selfplay* s, int which, void** h, bool allRows) {
+    uint64_t* clk = hm_sp_leg_clock_net(s->sp);      // both launches of a two-network iteration fall into the one interval
     if (!s->net2)
-        return hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8, h[0], h[1], h[2], h[3], h[4], s->sN);
-    if (int rc = hm_net_forward_groups(s->io.net, s->io.planes[which], s->G * 8, s->d_rowsNet[0][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN)) return rc;
-    return hm_net_forward_groups(s->net2, s->io.planes[which], s->G * 8, s->d_rowsNet[1][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN);
+        return hm_net_forward_groups_timed(s->io.net, s->io.planes[which], s->G * 8, allRows ? nullptr : s->d_rows[which], 8, h[0], h[1], h[2], h[3], h[4], s->sN, clk);
+    if (int rc = hm_net_forward_groups_timed(s->io.net, s->io.planes[which], s->G * 8, s->d_rowsNet[0][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN, clk)) return rc;
+    return hm_net_forward_groups_timed(s->net2, s->io.planes[which], s->G * 8, s->d_rowsNet[1][which], 8, h[0], h[1], h[2], h[3], h[4], s->sN, clk);
 }
 
 
@@ -335,11 +336,13 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     // No game can finish before it has collected minTarget nodes, i.e. floor(minTarget / 8) batches: the
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
     const int noPollBefore = minTarget / 8 - 1;
-    // Leg timings (HIP events on the launch streams) are sampled: event records are not free.  The samples of one search
-    // are averaged and stand for all of its iterations.
+    // Leg timings.  Native evaluator: the device-side leg clock (hm_sp_leg_times) -- every launch, graph-replayed ones included,
+    // stamps its own start and end, so the totals are exact and cost the host nothing.  Callback evaluator: HIP events on the null
+    // stream around each leg.
     int harvested = 0, nSamples = 0;
     double sum[3] = {0.0, 0.0, 0.0};
-    auto is_timed = [&](int it) { return !native || (s->graphState == 1 ? (it == 3 || it == 6) : (it & 7) == 0); };
+    auto is_timed = [&](int) { return !native; };
+    if (native) if (int rc = hm_sp_leg_times(s->sp, nullptr, nullptr, 1)) return rc;
     auto harvest = [&](int upto) {                 // leg timings of the sampled iterations in [harvested, upto)
         for (int it = harvested; it < upto; ++it) {
             if (!is_timed(it)) continue;
@@ -354,8 +357,8 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     };
     if (native && s->graphState == 0) build_step_graph(s, allRows);
     while (active > 0) {
-        // Leg timings are sampled on eager iterations (the first GRAPH_ITERS of every search); after that the loop replays the
-        // captured graph, GRAPH_ITERS iterations per launch, polling the active-game count once per launch.
+        // The first GRAPH_ITERS iterations of every search are enqueued eagerly; after that the loop replays the captured graph,
+        // GRAPH_ITERS iterations per launch, polling the active-game count once per launch.
         if (native && s->graphState == 1 && iters >= GRAPH_ITERS && which == 0) {
             if (hipGraphLaunch(s->stepGraph, s->sT) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipGraphLaunch failed");
             iters += GRAPH_ITERS;
@@ -416,7 +419,11 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         if (poll && !(native && s->graphState == 1)) harvest(iters);
         if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
     }
-    harvest(std::min(iters, s->graphState == 1 && native ? GRAPH_ITERS : iters));      // the stream was synchronised by the last poll
+    if (native) {                                  // the tree stream was synchronised by the last poll
+        double ms[3];
+        if (int rc = hm_sp_leg_times(s->sp, ms, nullptr, 0)) return rc;
+        s->res.collect_ms += ms[0]; s->res.eval_ms += ms[1]; s->res.process_ms += ms[2];
+    } else harvest(iters);
     if (nSamples > 0) {
         const double w = (double)iters / nSamples;
         s->res.collect_ms += w * sum[0]; s->res.eval_ms += w * sum[1]; s->res.process_ms += w * sum[2];

@@ -51,6 +51,8 @@ _SIGS = {
     "hm_sp_stop": (_i, [_vp, _vp, _vp]),
     "hm_sp_profile": (_i, [_vp, _i]),
     "hm_sp_profile_launches": (_i, [_vp, _i]),
+    "hm_sp_leg_times": (_i, [_vp, _vp, _vp, _i]),
+    "hm_sp_leg_clock_net": (_vp, [_vp]),
     "hm_sp_trace_select": (_i, [_i]),
     "hm_sp_trace": (_i, [_vp, _i]),
 }
@@ -156,6 +158,12 @@ class SearchEngine:
             if it % poll_every == 0 and active == 0:
                 break
         return it
+
+    def leg_times(self, reset=False):
+        """Device-clock totals since the last reset: (ms[collect, forward, process], launches[3]).  Synchronise first."""
+        ms, cnt = np.zeros(3, np.float64), np.zeros(3, np.uint64)
+        check(lib.hm_sp_leg_times(self.h, ms.ctypes.data, cnt.ctypes.data, int(reset)))
+        return ms, cnt
 
     def root_stats(self):
         G, E = self.G, self.max_edges

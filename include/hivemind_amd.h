@@ -207,6 +207,12 @@ int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, 
 /* active_games (host, optional): number of games still searching after this step (forces a sync). */
 int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void* d_pi_b, const void* d_wdl,
                   const void* d_moves_left, int* active_games, void* stream);
+/* Leg clock: exact device time (ms) and launch counts of k_collect / the forward / k_process since the last reset — every
+ * workgroup min-/max-es the constant 100 MHz device clock into the leg's interval, the next kernel in stream order folds it into a
+ * sum, so graph-replayed launches are covered too (ms3 / counts3 may be NULL).  The forward takes part when it is launched through
+ * hm_net_forward_groups_timed with hm_sp_leg_clock_net(sp). */
+int hm_sp_leg_times(hm_sp* sp, double* ms3, uint64_t* counts3, int reset);
+uint64_t* hm_sp_leg_clock_net(hm_sp* sp);
 /* Games still searching after the last hm_sp_process (synchronises). */
 int hm_sp_active(hm_sp* sp, int* active);
 /* Agent::root_edge_stats / root_q (agent.cc:1004-1024) for all games -> host arrays
@@ -276,6 +282,11 @@ int hm_net_forward(const hm_net* net, const void* d_planes, int n,
  * rows of group g are evaluated (d_group_rows from hm_sp_collect_counted), the rest are skipped. */
 int hm_net_forward_groups(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
                           void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream);
+/* As hm_net_forward_groups; the launch is also stamped into d_interval[0..1] = (start, end) of a leg clock
+ * (hm_sp_leg_clock_net), every workgroup min-/max-ing the 100 MHz device clock into it. */
+int hm_net_forward_groups_timed(const hm_net* net, const void* d_planes, int n, const int32_t* d_group_rows, int group,
+                                void* d_value, void* d_pi_a, void* d_pi_b, void* d_wdl, void* d_moves_left, void* stream,
+                                uint64_t* d_interval);
 /* Diagnostic variant: same launch, d_stamps[256] (device u64) receives the shader clock at the phase
  * boundaries of workgroup 0 (tools/profile_net.py). */
 int hm_net_profile(const hm_net* net, const void* d_planes, int n,

@@ -95,14 +95,22 @@ def test_collect_row_counts(hm):
     eng.begin_search(200)
     rows = torch.zeros(G, dtype=torch.int32, device="cuda")
     total = np.zeros(G, np.int64)
+    iters = 0
+    eng.leg_times(reset=True)
     for _ in range(2000):
         planes = eng.collect(rows_next=rows)
+        iters += 1
         r = rows.cpu().numpy()
         assert ((0 <= r) & (r <= 8)).all()
         total += r
         if eng.process(*_hash_eval_gpu(planes)) == 0:
             break
     st = eng.root_stats()
+    # leg clock: one k_collect and one k_process interval per iteration, each a plausible launch duration; no timed forward here
+    ms, cnt = eng.leg_times(reset=True)
+    assert cnt[0] == cnt[2] == iters and cnt[1] == 0, (cnt, iters)
+    assert 0.005 * iters < ms[0] < 50.0 * iters and 0.005 * iters < ms[2] < 50.0 * iters and ms[1] == 0.0, (ms, iters)
+    assert eng.leg_times()[1].sum() == 0
     # rows written after a game's last processed batch (aborted lookahead) are counted by collect but not evaluated
     assert (total >= st["info"][:, 2]).all() and (total - st["info"][:, 2] <= 8).all(), (total, st["info"][:, 2])
 

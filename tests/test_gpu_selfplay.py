@@ -139,6 +139,11 @@ def test_selfplay_full_network_configs3(hm, tmp_path):
     kw = dict(games=8, nodes=64, seed=4, concurrent_games=8, max_macro_plies=24)
     res, rec, cnt = _run(hm, net, **kw)
     assert res.games == 8 and cnt == res.samples > 0 and res.eval_rows > 0
+    # leg clock: per-iteration device time of every leg is a plausible launch duration and the legs fit into the search wall time
+    it = res.search_iterations
+    for ms in (res.collect_ms, res.eval_ms, res.process_ms):
+        assert 0.005 < ms / it < 20.0, (res.collect_ms, res.eval_ms, res.process_ms, it)
+    assert max(res.collect_ms, res.eval_ms) + res.process_ms < 1.05e3 * res.search_seconds
     games = _by_game(hm, tmp_path, rec, cnt, "full.hvm")
     for ss in games.values():
         for s in ss:
