@@ -1977,6 +1977,36 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
     }
 }
 
+// Principal variations (Agent::extract_pv_from_child, agent.cc:1218-1290): line l starts with root edge childIdx[l] and then follows
+// the final-move rule (best_move_index; its fallbacks never fire on a node with children) through expanded nodes, maxDepth joint
+// actions at most.  One lane per line; out: moves[l][depth][2], lens[l], and the first child's solver type / end-in-ply for
+// format_uci_score (agent.cc:48-78).
+__global__ void k_pv(Pools pl, Params prm, int game, int nLines, const int* childIdx, int maxDepth, u32* moves, int* lens, int* ctype, int* cend) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nLines) return;
+    G s = make_view(pl, prm, game);
+    lens[l] = 0; ctype[l] = 0; cend[l] = 0;
+    if (s.g->root < 0) return;
+    const Node& r = s.nodes[s.g->root];
+    const int ci = childIdx[l];
+    if (!(r.flags & F_EXPANDED) || ci < 0 || ci >= r.expanded) return;
+    u32* out = moves + (size_t)l * maxDepth * 2;
+    const Edge& e0 = edges_of(s, r)[ci];
+    out[0] = e0.moveA; out[1] = e0.moveB;
+    int cur = e0.child, len = 1;
+    ctype[l] = s.nodes[cur].type; cend[l] = s.nodes[cur].endInPly;
+    for (; len < maxDepth; ++len) {
+        const Node& n = s.nodes[cur];
+        if (!(n.flags & F_EXPANDED) || n.expanded <= 0) break;
+        const int b = best_move_index(s, n, prm.qVetoDelta, prm.qValueWeight);
+        if (b < 0) break;
+        const Edge& e = edges_of(s, n)[b];
+        out[2 * len] = e.moveA; out[2 * len + 1] = e.moveB;
+        cur = e.child;
+    }
+    lens[l] = len;
+}
+
 // Board::push_move of the chosen joint action + team / time-advantage flip (selfplay.cc:694-716)
 __global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* moveA, const u32* moveB, const uint8_t* mask, int* err) {
     __shared__ RulesTab s_rt;
@@ -2072,7 +2102,9 @@ __global__ __launch_bounds__(64) void k_game_state(Pools pl, Params prm, hm_boar
 // Raw-policy opening support (selfplay.cc:277-376): per game, actions (+pass) and probabilities of
 // both boards from the net's policy heads; plus action_leads_to_terminal for a proposed action.
 struct RawOut { u32* moves; float* probs; int* counts; uint8_t* caps; uint8_t* onTurn; };   // [g][2][HM_MAX_MOVES]
-__global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const uint16_t* piA, const uint16_t* piB, RawOut o) {
+// allMoves != 0: the UCI `policy` listing (uci.cc:306-393) -- every legal move, rook / bishop promotions kept with logit -inf
+// (get_fast_policy_index returns -1 for them, utils.h:183-216) instead of being dropped as the search does.
+__global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const uint16_t* piA, const uint16_t* piB, RawOut o, int allMoves) {
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     stage_table(&s_rt, pl.rules);
@@ -2096,7 +2128,7 @@ __global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const u
             for (int i = 0; i < n; ++i) {
                 const u32 m = list[i];
                 const bool bad = (m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP);
-                if (!bad) list[k++] = m;
+                if (!bad || allMoves) list[k++] = m;
             }
             n = k;
         }
@@ -2111,6 +2143,7 @@ __global__ __launch_bounds__(64) void k_raw_policy(Pools pl, Params prm, const u
                 int idx;
                 if (m == 0) idx = 0;
                 else if ((m & (15u << 12)) == HM_MT_DROP) idx = pl.polDrop[(stm * 64 + (m & 63)) * 8 + ((m >> 16) & 63)];
+                else if ((m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP)) idx = -1;
                 else {
                     const int knight = ((m & (15u << 12)) == HM_MT_PROMOTION && ((m >> 16) & 63) == HM_KNIGHT) ? 1 : 0;
                     idx = pl.polNormal[((stm * 64 + ((m >> 6) & 63)) * 64 + (m & 63)) * 2 + knight];
@@ -2231,6 +2264,8 @@ struct hm_sp {
     int nGames;
     int maxEdges;
     std::vector<void*> allocs;
+    int* d_pv = nullptr;                 // hm_sp_pv_lines scratch (grown on demand)
+    size_t pvInts = 0;
     // device outputs
     RootOut ro;
     u64* d_rootHash;
@@ -2580,6 +2615,31 @@ int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, i
     return 0;
 }
 int hm_sp_max_edges(const hm_sp* sp) { return sp ? sp->maxEdges : 0; }
+// Principal variations of one game's finished (or stopped) search: see k_pv.  child_idx[n_lines] are root edge indices (the caller
+// orders them: visit count, solver-aware best move first -- agent.cc:917-940); moves[n_lines][max_depth][2], lens / child_type /
+// child_end_in_ply [n_lines].
+int hm_sp_pv_lines(hm_sp* sp, int game, int n_lines, const int* child_idx, int max_depth, hm_move* moves, int* lens, int* child_type, int* child_end_in_ply) {
+    if (!sp || !child_idx || !moves || !lens) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (game < 0 || game >= sp->nGames || n_lines < 1 || n_lines > 500 || max_depth < 1 || max_depth > 64) return hm_fail(HM_ERR_INVALID, "game / n_lines (1..500) / max_depth (1..64) out of range");
+    const size_t nInts = (size_t)n_lines * (4 + 2 * (size_t)max_depth);
+    if (sp->pvInts < nInts) {                               // idx | lens | type | end | moves
+        int* d = nullptr;
+        if (int rc = dalloc(sp, &d, nInts)) return rc;
+        sp->d_pv = d; sp->pvInts = nInts;
+    }
+    int* d = sp->d_pv;
+    HIPCHK(hipMemcpy(d, child_idx, sizeof(int) * n_lines, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pv, dim3((n_lines + 63) / 64), dim3(64), 0, 0, sp->pl, sp->prm, game, n_lines, d, max_depth,
+                       reinterpret_cast<u32*>(d + 4 * (size_t)n_lines), d + n_lines, d + 2 * (size_t)n_lines, d + 3 * (size_t)n_lines);
+    HIPCHK(hipGetLastError());
+    std::vector<int> h(nInts);
+    HIPCHK(hipMemcpy(h.data(), d, sizeof(int) * nInts, hipMemcpyDeviceToHost));
+    std::memcpy(lens, h.data() + n_lines, sizeof(int) * n_lines);
+    if (child_type) std::memcpy(child_type, h.data() + 2 * (size_t)n_lines, sizeof(int) * n_lines);
+    if (child_end_in_ply) std::memcpy(child_end_in_ply, h.data() + 3 * (size_t)n_lines, sizeof(int) * n_lines);
+    std::memcpy(moves, h.data() + 4 * (size_t)n_lines, sizeof(int) * 2 * (size_t)max_depth * n_lines);
+    return 0;
+}
 
 // diagnostic (-DHM_SEARCH_TRACE builds): select the traced game slot (clears the log) / read the log
 int hm_sp_trace_select(int game) {
@@ -2680,10 +2740,13 @@ int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out
     return 0;
 }
 int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps, int* counts, uint8_t* on_turn) {
+    return hm_sp_policy_listing(sp, d_pi_a, d_pi_b, moves, probs, caps, counts, on_turn, 0);
+}
+int hm_sp_policy_listing(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps, int* counts, uint8_t* on_turn, int all_moves) {
     if (!sp || !d_pi_a || !d_pi_b || !moves || !probs || !counts) return hm_fail(HM_ERR_INVALID, "null argument");
     const size_t G_ = sp->nGames;
     hipLaunchKernelGGL(k_raw_policy, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, static_cast<const uint16_t*>(d_pi_a),
-                       static_cast<const uint16_t*>(d_pi_b), sp->raw);
+                       static_cast<const uint16_t*>(d_pi_b), sp->raw, all_moves);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(moves, sp->raw.moves, 4 * G_ * 2 * HM_MAX_MOVES, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(probs, sp->raw.probs, 4 * G_ * 2 * HM_MAX_MOVES, hipMemcpyDeviceToHost));

@@ -10,10 +10,11 @@
 // (history, repetition keys), `go` runs the search and prints the solver-aware best move (get_best_move_idx_with_q_weight,
 // node.h:656-754 — computed on the device, hm_sp_root_stats info[12]).
 // Built: uci, isready, ucinewgame, position startpos|fen ... [moves <1|2><uci> ...], go nodes N | movetime T (| neither = 1 s),
-// stop, setoption name {Team, Mode, DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,
-// PWExponentPermille, Transpositions} (Hash, MultiPV, Ponder are accepted and reported as the reference does), quit.
-// Not built (documented in DESIGN.md): pondering / ponderhit, tree reuse between moves, multi-PV lines and PV extraction
-// beyond the best move and the `policy` debug command.  `go movetime` follows the reference's polling loop (early exit on a
+// stop, setoption name {Team, Mode, MultiPV, Ponder, DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,
+// PWExponentPermille, Transpositions} (Hash is accepted and reported as the reference does), policy (uci.cc:306-393), quit.
+// The final `info` lines carry MultiPV principal variations (agent.cc:917-965, 1218-1290; walked on the device by hm_sp_pv_lines)
+// and `bestmove` carries the ponder move (agent.cc:1054-1113) when Ponder is on.
+// Not built (documented in DESIGN.md): `go ponder` / ponderhit (a search that runs until told to stop) and tree reuse between moves.  `go movetime` follows the reference's polling loop (early exit on a
 // solved root / forced mate, early stopping on an insurmountable visit lead, time extension).  A search is synchronous: the command returns when `bestmove` has been printed.
 #include <hip/hip_runtime.h>
 
@@ -114,6 +115,41 @@ bool parse_fen(const HostTables& h, const std::string& fen, hm_pos* out) {
     return true;
 }
 
+// Position::fen(false, true) (Fairy-Stockfish position.cpp:637-768) for the bughouse subset: placement with '~' after promoted pieces,
+// the pocket in brackets (white then black, queen down to pawn), side, castling, en passant, halfmove clock, fullmove number.
+std::string fen_text(const hm_pos& p) {
+    static const char pc[] = "PNBRQK";
+    std::string s;
+    for (int r = 7; r >= 0; --r) {
+        int empty = 0;
+        for (int f = 0; f < 8; ++f) {
+            const uint64_t b = 1ULL << (r * 8 + f);
+            int t = -1;
+            for (int k = 0; k < 6; ++k) if (p.by_type[k] & b) t = k;
+            if (t < 0) { ++empty; continue; }
+            if (empty) { s += (char)('0' + empty); empty = 0; }
+            s += (p.by_color[1] & b) ? (char)std::tolower((unsigned char)pc[t]) : pc[t];
+            if (p.promoted & b) s += '~';
+        }
+        if (empty) s += (char)('0' + empty);
+        if (r > 0) s += '/';
+    }
+    s += '[';
+    for (int c = 0; c < 2; ++c)
+        for (int pt = 4; pt >= 0; --pt) s += std::string(p.hand[c][pt], c ? (char)std::tolower((unsigned char)pc[pt]) : pc[pt]);
+    s += ']';
+    s += p.stm == 0 ? " w " : " b ";
+    if (p.castling & HM_WHITE_OO) s += 'K';
+    if (p.castling & HM_WHITE_OOO) s += 'Q';
+    if (p.castling & HM_BLACK_OO) s += 'k';
+    if (p.castling & HM_BLACK_OOO) s += 'q';
+    if (!(p.castling & (HM_WHITE_OO | HM_WHITE_OOO | HM_BLACK_OO | HM_BLACK_OOO))) s += '-';
+    if (p.ep < 64) { s += ' '; s += (char)('a' + (p.ep & 7)); s += (char)('1' + (p.ep >> 3)); s += ' '; }
+    else s += " - ";
+    s += std::to_string((int)p.rule50) + " " + std::to_string(1 + ((int)p.game_ply - (p.stm == 1 ? 1 : 0)) / 2);
+    return s;
+}
+
 std::string trim(const std::string& s) {
     const size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
     return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
@@ -196,6 +232,7 @@ struct hm_uci {
     hm_pos* d_pos = nullptr;          // scratch for legal-move queries
     hm_move* d_moves = nullptr;
     uint32_t* d_counts = nullptr;
+    hm_board* d_board = nullptr;      // `policy`: the position handed to the plane encoder
     hipStream_t sN = nullptr;
     std::string out;
 };
@@ -341,13 +378,101 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
     if (count <= 0 || best < 0 || best >= count) { u->out += "bestmove (none)\n"; return; }
     const std::string bestText = "(" + uci_text(mA[best]) + "," + uci_text(mB[best]) + ")";
     const int nps = ms > 0 ? (int)(nodesDone * 1000.0 / ms) : 0;
-    char line[512];
-    std::snprintf(line, sizeof line, "info depth %d %s nodes %d nps %d hashfull 0 tbhits 0 time %d pv %s\n", depth,
-                  uci_score(info[14], info[15], q[best]).c_str(), nodesDone, nps, (int)ms, bestText.c_str());
-    u->out += line;
+    // final info lines (agent.cc:917-965): root children by visit count (the reference's std::sort and comparator), the solver-aware
+    // best move first, MultiPV lines at most, each with its principal variation (20 joint actions at most, walked on the device)
+    std::vector<size_t> order((size_t)count);
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return visits[a] > visits[b]; });
+    {
+        auto it = std::find(order.begin(), order.end(), (size_t)best);
+        if (it != order.end() && it != order.begin()) { order.erase(it); order.insert(order.begin(), (size_t)best); }
+    }
+    constexpr int PV_DEPTH = 20;
+    const int numPVs = std::min(u->multiPV, count);
+    std::vector<int> childIdx((size_t)numPVs), lens((size_t)numPVs), ctype((size_t)numPVs), cend((size_t)numPVs);
+    std::vector<hm_move> pvMoves((size_t)numPVs * PV_DEPTH * 2);
+    for (int k = 0; k < numPVs; ++k) childIdx[k] = (int)order[k];
+    if (hm_sp_pv_lines(u->sp, 0, numPVs, childIdx.data(), PV_DEPTH, pvMoves.data(), lens.data(), ctype.data(), cend.data())) {
+        u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n";
+        return;
+    }
+    auto joint_text = [&](int k, int d) { const hm_move* m = &pvMoves[((size_t)k * PV_DEPTH + d) * 2]; return "(" + uci_text(m[0]) + "," + uci_text(m[1]) + ")"; };
+    for (int k = 0; k < numPVs; ++k) {
+        std::string s = "info depth " + std::to_string(depth);
+        if (u->multiPV > 1) s += " multipv " + std::to_string(k + 1);
+        s += " " + uci_score(ctype[k], cend[k], q[childIdx[k]]) + " nodes " + std::to_string(nodesDone) + " nps " + std::to_string(nps)
+             + " hashfull 0 tbhits 0 time " + std::to_string((int)ms);
+        for (int d = 0; d < lens[k]; ++d) s += (d == 0 ? " pv " : " ") + joint_text(k, d);
+        u->out += s + "\n";
+    }
+    char line[256];
     std::snprintf(line, sizeof line, "info string rejected selection attempts %d (same batch %d, pending evaluation %d)\n", info[3] + info[4], info[3], info[4]);
     u->out += line;
-    u->out += "bestmove " + bestText + "\n";
+    // extract_ponder_move (agent.cc:1054-1113): the best child's own best reply = the second joint action of line 1
+    if (u->ponder && numPVs > 0 && lens[0] >= 2) u->out += "bestmove " + bestText + " ponder " + joint_text(0, 1) + "\n";
+    else u->out += "bestmove " + bestText + "\n";
+}
+
+static float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, ex = (h >> 10) & 31u, man = h & 1023u;
+    uint32_t bits;
+    if (ex == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; uint32_t m = man; do { ++e; m <<= 1; } while (!(m & 1024u)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 1023u) << 13); }
+    } else if (ex == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((ex + 112u) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// UCI::policy (uci.cc:306-393): one forward of the current position as the team sees it; value, WDL (win draw loss), predicted plies,
+// and per board the legal moves + pass with their normalised policy, most probable first.
+static void uci_policy(hm_uci* u) {
+    auto fail = [&](const char* what) { u->out += std::string("info string policy failed: ") + what + ": " + hm_last_error() + "\n"; };
+    const uint8_t team = (uint8_t)u->team, adv = u->sit ? 1 : 0;
+    if (hm_sp_set_side(u->sp, &team, &adv)) return fail("set_side");
+    hm_board hb;
+    int flags = 0;
+    if (!u->d_board && hipMalloc(reinterpret_cast<void**>(&u->d_board), sizeof(hm_board)) != hipSuccess) { u->out += "info string policy failed: hipMalloc\n"; return; }
+    if (hm_sp_game_state(u->sp, &hb, &flags, u->d_board)) return fail("game_state");
+    // the evaluator sees batches of 8 rows: row 0 is the position, the rest of the buffer is cleared
+    if (hipMemset(u->io.planes[0], 0, (size_t)8 * HM_NB_PLANES * 64 * sizeof(uint16_t)) != hipSuccess) { u->out += "info string policy failed: hipMemset\n"; return; }
+    if (hm_encode_planes(u->d_board, 1, HM_DT_F16, u->io.planes[0], nullptr)) return fail("encode_planes");
+    if (hipDeviceSynchronize() != hipSuccess) { u->out += "info string policy failed: device\n"; return; }
+    const int rc = u->net ? hm_net_forward(u->net, u->io.planes[0], 8, u->io.value, u->io.pi_a, u->io.pi_b, u->io.wdl, u->io.moves_left, nullptr)
+                          : u->fn(u->user, 0, 8);
+    if (rc) { u->out += "Inference failed\n"; return; }
+    if (hipDeviceSynchronize() != hipSuccess) { u->out += "info string policy failed: device\n"; return; }
+    uint16_t hv = 0, hml = 0, hwdl[3] = {0, 0, 0};
+    if (hipMemcpy(&hv, u->io.value, 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&hml, u->io.moves_left, 2, hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy(hwdl, u->io.wdl, 6, hipMemcpyDeviceToHost) != hipSuccess) { u->out += "info string policy failed: hipMemcpy\n"; return; }
+    std::vector<hm_move> moves(2 * HM_MAX_MOVES);
+    std::vector<float> probs(2 * HM_MAX_MOVES);
+    int counts[2] = {0, 0};
+    uint8_t onTurn[2] = {0, 0};
+    if (hm_sp_policy_listing(u->sp, u->io.pi_a, u->io.pi_b, moves.data(), probs.data(), nullptr, counts, onTurn, 1)) return fail("policy_listing");
+    std::ostringstream os;                                  // the reference prints through std::cout's default float format
+    const float wdl[3] = {half_to_float(hwdl[0]), half_to_float(hwdl[1]), half_to_float(hwdl[2])};
+    os << "Value: " << half_to_float(hv) << "\n";
+    const float maxWdl = std::max({wdl[0], wdl[1], wdl[2]});
+    const float lossExp = std::exp(wdl[0] - maxWdl), drawExp = std::exp(wdl[1] - maxWdl), winExp = std::exp(wdl[2] - maxWdl);
+    const float wdlTotal = lossExp + drawExp + winExp;
+    os << "WDL: " << winExp / wdlTotal << " " << drawExp / wdlTotal << " " << lossExp / wdlTotal << "\n";
+    os << "Predicted plies to end: " << half_to_float(hml) * 100.0f << "\n\n";
+    for (int b = 0; b < 2; ++b) {
+        os << "Board " << (b == 0 ? 'A' : 'B') << " (" << fen_text(hb.pos[b]) << "):\n";
+        if (onTurn[b]) {
+            const hm_move* mv = &moves[(size_t)b * HM_MAX_MOVES];
+            const float* pr = &probs[(size_t)b * HM_MAX_MOVES];
+            std::vector<size_t> idx((size_t)counts[b]);
+            for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](size_t i1, size_t i2) { return pr[i1] > pr[i2]; });     // argsort, utils.h:26-34
+            for (const size_t i : idx) os << "  " << uci_text(mv[i]) << ": " << pr[i] << "\n";
+        } else os << "  (not our turn)\n";
+        if (b == 0) os << "\n";
+    }
+    u->out += os.str();
 }
 
 static void uci_setoption(hm_uci* u, std::istringstream& is) {   // uci.cc:239-296
@@ -441,6 +566,7 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
     else if (token == "setoption") uci_setoption(u, is);
     else if (token == "position") uci_position(u, is);
     else if (token == "ucinewgame") { hm_board b; hm_board_startpos(&b); (void)uci_set_position(u, b); }   // new_game: search state is per `go` here
+    else if (token == "policy") uci_policy(u);
     else if (token == "stop" || token == "ponderhit") {}          // searches are synchronous: nothing is running between commands
     else if (token == "quit") quit = true;
     if ((int64_t)u->out.size() + 1 > cap || !out) return quit ? HM_UCI_QUIT : -(int64_t)u->out.size() - 1;
@@ -448,6 +574,16 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
     const int64_t n = (int64_t)u->out.size();
     u->out.clear();
     return quit ? HM_UCI_QUIT : n;
+}
+
+// Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text
+// length, or -(needed size) when cap is too small.
+int hm_board_fen(const hm_board* b, int board, char* out, int cap) {
+    if (!b || board < 0 || board > 1) return hm_fail(HM_ERR_INVALID, "null board / board index not 0 or 1");
+    const std::string s = fen_text(b->pos[board]);
+    if (!out || (int)s.size() + 1 > cap) return -(int)s.size() - 1;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 
 // the current game position (after the last `position` command) for tests and GUIs that mirror the board
@@ -464,6 +600,7 @@ int hm_uci_destroy(hm_uci* u) {
     if (u->d_pos) (void)hipFree(u->d_pos);
     if (u->d_moves) (void)hipFree(u->d_moves);
     if (u->d_counts) (void)hipFree(u->d_counts);
+    if (u->d_board) (void)hipFree(u->d_board);
     delete u;
     return 0;
 }

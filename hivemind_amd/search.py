@@ -43,6 +43,7 @@ _SIGS = {
     "hm_sp_apply": (_i, [_vp, _vp, _vp, _vp]),
     "hm_sp_game_state": (_i, [_vp, _vp, _vp, _vp]),
     "hm_sp_raw_policy": (_i, [_vp] * 8),
+    "hm_sp_policy_listing": (_i, [_vp] * 8 + [_i]),
     "hm_sp_action_terminal": (_i, [_vp, _vp, _vp, _vp]),
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
     "hm_sp_classify": (_i, [_vp, _vp, _vp]),
@@ -52,6 +53,7 @@ _SIGS = {
     "hm_sp_profile": (_i, [_vp, _i]),
     "hm_sp_profile_launches": (_i, [_vp, _i]),
     "hm_sp_leg_times": (_i, [_vp, _vp, _vp, _i]),
+    "hm_sp_pv_lines": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "hm_sp_leg_clock_net": (_vp, [_vp]),
     "hm_sp_trace_select": (_i, [_i]),
     "hm_sp_trace": (_i, [_vp, _i]),

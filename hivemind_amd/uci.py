@@ -17,6 +17,7 @@ _SIGS = {
     "hm_uci_command": (C.c_int64, [_vp, C.c_char_p, _vp, C.c_int64]),
     "hm_uci_board": (_i, [_vp, _vp]),
     "hm_uci_destroy": (_i, [_vp]),
+    "hm_board_fen": (_i, [_vp, _i, C.c_char_p, _i]),
     "hm_insurmountable_visit_lead": (_i, [C.c_float, C.c_float, C.c_float]),
     "hm_time_manager_create": (_vp, [_i]),
     "hm_time_manager_poll": (_i, [_vp, C.c_double, _i, _i, _vp, _vp, _i, _vp, _vp, C.POINTER(C.c_double), _vp, _i]),
@@ -26,6 +27,17 @@ for _n, (_r, _a) in _SIGS.items():
     _f = getattr(lib, _n)
     _f.restype, _f.argtypes = _r, _a
 _lib.EXPORTED_SYMBOLS = tuple(_lib.EXPORTED_SYMBOLS) + tuple(_SIGS)
+
+
+def board_fen(board, b: int) -> str:
+    """Board::fen(b) of a compact board record (numpy BOARD_DTYPE, one element); host-only."""
+    import numpy as np
+    board = np.ascontiguousarray(board)
+    buf = C.create_string_buffer(160)
+    n = lib.hm_board_fen(board.ctypes.data, int(b), buf, len(buf))
+    if n < 0:
+        raise ValueError("hm_board_fen failed")
+    return buf.value.decode()
 
 
 class Uci:

@@ -227,6 +227,12 @@ int hm_sp_active(hm_sp* sp, int* active);
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
                      float* root_q, int* info, int max_edges);
+/* Principal variations of one game's search (Agent::extract_pv_from_child, agent.cc:1218-1290): line l starts with root edge
+ * child_idx[l] and follows the final-move rule through expanded nodes, max_depth joint actions at most.  The caller orders the
+ * root edges (visit count, solver-aware best move first: agent.cc:917-940).  moves[n_lines][max_depth][2]; lens, child_type and
+ * child_end_in_ply [n_lines] (the last two feed format_uci_score, agent.cc:48-78; optional). */
+int hm_sp_pv_lines(hm_sp* sp, int game, int n_lines, const int* child_idx, int max_depth, hm_move* moves, int* lens,
+                   int* child_type, int* child_end_in_ply);
 /* Board::push_move of the chosen joint action, then team / time-advantage flip (selfplay.cc:694-716).
  * HM_ERR_OVERFLOW when a game's history pool is full (nothing is applied to that game). */
 int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask);
@@ -237,6 +243,10 @@ int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out
  * masked-softmax probabilities from policy heads [n_games, 4672] (one row per game). */
 int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps,
                      int* counts, uint8_t* on_turn);
+/* The same listing for the UCI `policy` command (uci.cc:306-393): all_moves != 0 keeps rook / bishop promotions in the list with
+ * probability 0 (get_fast_policy_index has no plane for them, utils.h:183-216) instead of dropping them as the search does. */
+int hm_sp_policy_listing(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps,
+                         int* counts, uint8_t* on_turn, int all_moves);
 /* action_leads_to_terminal (selfplay.cc:378-390). */
 int hm_sp_action_terminal(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, int* out);
 /* Test hook: Board::is_checkmate x4, in-check x2, classify_terminal_position x2 and hash keys for
@@ -473,11 +483,13 @@ int hm_move_uci(hm_move move, char* out, int cap);
 /* `bestmove (<moveA>,<moveB>)` with the solver-aware move rule          */
 /* (agent.cc:1031-1049).  Built: uci, isready, ucinewgame, position      */
 /* startpos|fen [moves <1|2><uci>...], go, stop, setoption (Team, Mode,  */
-/* DrawContemptPermille, PWCoefficientPermille, RootPWCoefficientPermille,*/
-/* PWExponentPermille, Transpositions; Hash / MultiPV / Ponder accepted), */
-/* quit; `go movetime` with the reference's early exit / early stopping /  */
-/* time extension rules.  Not built: pondering, tree reuse, multi-PV / PV  */
-/* lines, the `policy` command.                                            */
+/* MultiPV, Ponder, DrawContemptPermille, PWCoefficientPermille,          */
+/* RootPWCoefficientPermille, PWExponentPermille, Transpositions; Hash      */
+/* accepted), policy (uci.cc:306-393), quit; `go movetime` with the         */
+/* reference's early exit / early stopping / time extension rules; final    */
+/* `info` lines with MultiPV principal variations (agent.cc:917-965,        */
+/* 1218-1290) and `bestmove ... ponder ...` (agent.cc:1054-1113).           */
+/* Not built: `go ponder` / ponderhit, tree reuse between moves.            */
 /* ================================================================== */
 typedef struct hm_uci hm_uci;
 #define HM_UCI_QUIT (-1000000)
@@ -489,6 +501,9 @@ int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* 
 int64_t hm_uci_command(hm_uci* uci, const char* line, char* out, int64_t cap);
 /* The current game position (after the last `position`), team / time_adv = the Team / Mode options. */
 int hm_uci_board(hm_uci* uci, hm_board* out);
+/* Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text
+ * length, or -(needed size) when cap is too small. */
+int hm_board_fen(const hm_board* board_pair, int board, char* out, int cap);
 int hm_uci_destroy(hm_uci* uci);
 /* SearchParams::has_insurmountable_visit_lead (search/search_params.h:322-326). */
 int hm_insurmountable_visit_lead(float best_visits, float projected_second_visits, float factor);

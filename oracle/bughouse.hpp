@@ -375,6 +375,40 @@ struct Pos {
         return k;
     }
 
+    // Position::fen(false, true) (position.cpp:637-768), bughouse subset: placement with '~' after promoted pieces, [hand] (white
+    // then black, queen down to pawn), side, castling, ep square, rule50, fullmove number
+    std::string fen() const {
+        static const char pcs[] = " PNBRQK";
+        std::string s;
+        for (int r = 7; r >= 0; --r) {
+            int empty = 0;
+            for (int f = 0; f < 8; ++f) {
+                const int sq = r * 8 + f, pc = board[sq];
+                if (!pc) { ++empty; continue; }
+                if (empty) { s += (char)('0' + empty); empty = 0; }
+                const char ch = pcs[pc_type(pc)];
+                s += pc_color(pc) == BLACK ? (char)tolower((unsigned char)ch) : ch;
+                if (promoted & sq_bb(sq)) s += '~';
+            }
+            if (empty) s += (char)('0' + empty);
+            if (r > 0) s += '/';
+        }
+        s += '[';
+        for (int c = WHITE; c <= BLACK; ++c)
+            for (int pt = QUEEN; pt >= PAWN; --pt) s += std::string((size_t)hand[c][pt], c == BLACK ? (char)tolower((unsigned char)pcs[pt]) : pcs[pt]);
+        s += ']';
+        s += stm == WHITE ? " w " : " b ";
+        if (castling & WHITE_OO) s += 'K';
+        if (castling & WHITE_OOO) s += 'Q';
+        if (castling & BLACK_OO) s += 'k';
+        if (castling & BLACK_OOO) s += 'q';
+        if (!castling) s += '-';
+        if (ep != SQ_NONE) { s += ' '; s += (char)('a' + (ep & 7)); s += (char)('1' + (ep >> 3)); s += ' '; }
+        else s += " - ";
+        s += std::to_string(rule50) + " " + std::to_string(1 + (gamePly - (stm == BLACK ? 1 : 0)) / 2);
+        return s;
+    }
+
     // FEN (position.cpp:232-470), bughouse subset: placement[hand] stm castling ep rule50 fullmove
     void set_fen(const std::string& fen) {
         clear();

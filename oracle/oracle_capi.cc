@@ -31,6 +31,12 @@ void* ora_board_new() { return new Board(); }
 void* ora_board_clone(void* h) { return new Board(*static_cast<Board*>(h)); }
 void ora_board_free(void* h) { delete static_cast<Board*>(h); }
 void ora_board_set(void* h, const char* fen) { static_cast<Board*>(h)->set(fen); }
+int ora_fen(void* h, int b, char* buf, int cap) {
+    const std::string s = static_cast<Board*>(h)->pos[b].fen();
+    if ((int)s.size() + 1 > cap) return -1;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
 void ora_board_set_fen(void* h, int b, const char* fen) { static_cast<Board*>(h)->set_fen(b, fen); }
 // positions from a compact state; history restarts here (like Board::set_fen)
 void ora_board_from_compact(void* h, const hm_board* c) {
@@ -178,6 +184,16 @@ int ora_search_edges(void* sp, uint32_t* moveA, uint32_t* moveB, int* visits, fl
 }
 float ora_search_root_q(void* sp) { return static_cast<Search*>(sp)->root_q(); }
 int ora_search_best_move(void* sp) { return static_cast<Search*>(sp)->best_move_index(); }
+// pv_lines: out_idx / out_type / out_end / out_len [multi_pv], out_q [multi_pv], out_moves [multi_pv][max_depth][2]; returns the line count
+int ora_search_pv_lines(void* sp, int multi_pv, int max_depth, int* out_idx, int* out_type, int* out_end, int* out_len, float* out_q, uint32_t* out_moves) {
+    const auto lines = static_cast<Search*>(sp)->pv_lines(multi_pv, max_depth);
+    for (size_t l = 0; l < lines.size(); ++l) {
+        out_idx[l] = lines[l].childIdx; out_type[l] = lines[l].childType; out_end[l] = lines[l].childEndInPly; out_q[l] = lines[l].q;
+        out_len[l] = (int)lines[l].moves.size() / 2;
+        for (size_t i = 0; i < lines[l].moves.size(); ++i) out_moves[l * (size_t)max_depth * 2 + i] = lines[l].moves[i];
+    }
+    return (int)lines.size();
+}
 void ora_search_info(void* sp, int* out /*8*/) {
     Search* s = static_cast<Search*>(sp);
     out[0] = s->nodesSearched; out[1] = s->evalRows; out[2] = s->evalCalls; out[3] = s->sameBatchCollisions;

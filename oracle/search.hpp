@@ -1010,6 +1010,47 @@ public:
         return out;
     }
     float root_q() const { return root ? root->Q() : 0.0f; }
+    // Final `info ... pv` lines of Agent::run_search (agent.cc:917-965): root children ordered by visit count (std::sort with the
+    // reference's comparator), the solver-aware best move pulled to the front, up to multiPV lines; each line's PV follows
+    // extract_pv_from_child (agent.cc:1218-1290): the root edge, then get_best_move_idx_with_q_weight (most-visited fallback)
+    // through expanded nodes, maxDepth joint actions at most.
+    struct PvLine { int childIdx, childType, childEndInPly; float q; std::vector<uint32_t> moves; /* moveA, moveB per depth */ };
+    std::vector<PvLine> pv_lines(int multiPV, int maxDepth = 20) const {
+        std::vector<PvLine> out;
+        if (!root || !root->isExpanded) return out;
+        const size_t numChildren = std::min(root->childVisits.size(), root->children.size());
+        std::vector<size_t> order(numChildren);
+        for (size_t i = 0; i < numChildren; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return root->childVisits[a] > root->childVisits[b]; });
+        const int solverIdx = root->get_best_move_idx_with_q_weight(cfg.qVetoDelta, cfg.qValueWeight);
+        if (solverIdx >= 0) {
+            auto it = std::find(order.begin(), order.end(), (size_t)solverIdx);
+            if (it != order.end() && it != order.begin()) { order.erase(it); order.insert(order.begin(), (size_t)solverIdx); }
+        }
+        const int numPVs = std::min(multiPV, (int)numChildren);
+        for (int k = 0; k < numPVs; ++k) {
+            const size_t ci = order[k];
+            PvLine line;
+            line.childIdx = (int)ci; line.q = root->qValues[ci];
+            const Node* cur = root->children[ci].get();
+            line.childType = cur ? (int)cur->nodeType : 0; line.childEndInPly = cur ? cur->endInPly : 0;
+            line.moves.push_back(root->gen.generated[ci].moveA); line.moves.push_back(root->gen.generated[ci].moveB);
+            for (int depth = 1; depth < maxDepth; ++depth) {
+                if (!cur || !cur->isExpanded || cur->children.empty() || cur->childVisits.empty()) break;
+                int best = cur->get_best_move_idx_with_q_weight(cfg.qVetoDelta, cfg.qValueWeight);
+                if (best < 0) {
+                    best = 0;
+                    int maxVisits = 0;
+                    for (size_t i = 0; i < cur->children.size() && i < cur->childVisits.size(); ++i)
+                        if (cur->childVisits[i] > maxVisits) { maxVisits = cur->childVisits[i]; best = (int)i; }
+                }
+                line.moves.push_back(cur->gen.generated[best].moveA); line.moves.push_back(cur->gen.generated[best].moveB);
+                cur = cur->children[best].get();
+            }
+            out.push_back(std::move(line));
+        }
+        return out;
+    }
     // index of the joint action Agent::run_search returns (agent.cc:859-889)
     int best_move_index() const {
         if (!root || !root->isExpanded) return -1;

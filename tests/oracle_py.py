@@ -119,6 +119,11 @@ class Board:
         self._f("compact")(self.h, team, int(adv), out.ctypes.data)
         return out
 
+    def fen(self, b):
+        buf = C.create_string_buffer(160)
+        (lib.ora_fen if self.p == "ora_" else ref.ref_fen)(self.h, b, buf, 160)
+        return buf.value.decode()
+
     def uci(self, b, m):
         buf = C.create_string_buffer(16)
         self._f("uci")(self.h, b, int(m), buf, 16)
@@ -176,6 +181,8 @@ lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp
 lib.ora_search_root_q.restype, lib.ora_search_root_q.argtypes = C.c_float, [_vp]
 lib.ora_search_info.restype, lib.ora_search_info.argtypes = None, [_vp, _vp]
 lib.ora_search_best_move.restype, lib.ora_search_best_move.argtypes = _i, [_vp]
+lib.ora_search_pv_lines.restype, lib.ora_search_pv_lines.argtypes = _i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.ora_fen.restype, lib.ora_fen.argtypes = _i, [_vp, _i, C.c_char_p, _i]
 lib.ora_search_trace.restype, lib.ora_search_trace.argtypes = _i, [_vp, _vp, _i]
 lib.ora_classify.restype, lib.ora_classify.argtypes = _i, [_vp, _i, _i, _i, _i]
 lib.ora_search_ctx_trace.restype, lib.ora_search_ctx_trace.argtypes = _i, [_vp, _vp, _i]
@@ -239,6 +246,14 @@ class Search:
 
     def root_q(self): return float(lib.ora_search_root_q(self.h))
     def best_move(self): return int(lib.ora_search_best_move(self.h))
+
+    def pv_lines(self, multi_pv=1, max_depth=20):
+        """-> list of dicts: child index / type / end-in-ply / q of each line and its joint actions [(moveA, moveB), ...]"""
+        idx, typ, end, ln = (np.zeros(multi_pv, np.int32) for _ in range(4))
+        q = np.zeros(multi_pv, np.float32)
+        mv = np.zeros((multi_pv, max_depth, 2), np.uint32)
+        n = lib.ora_search_pv_lines(self.h, multi_pv, max_depth, idx.ctypes.data, typ.ctypes.data, end.ctypes.data, ln.ctypes.data, q.ctypes.data, mv.ctypes.data)
+        return [dict(child=int(idx[l]), type=int(typ[l]), end_in_ply=int(end[l]), q=float(q[l]), moves=[(int(a), int(b)) for a, b in mv[l, :ln[l]]]) for l in range(n)]
 
 
 def hash_evaluator(planes):

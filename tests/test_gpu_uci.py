@@ -47,6 +47,10 @@ def _oracle_board(fen=None, moves=()):
     return b
 
 
+def _joint(a, b):
+    return "(" + O.move_uci(a) + "," + O.move_uci(b) + ")"
+
+
 def test_uci_handshake_and_options(hm):
     u = hm.Uci(DeviceHashNet(hm), max_nodes=2000)
     text, quit_ = u.command("uci")
@@ -103,13 +107,106 @@ def test_go_nodes_matches_oracle_search(hm, team, mode, moves, nodes):
     e = s.edges()
     best = s.best_move()
     want = "(" + O.move_uci(e["move_a"][best]) + "," + O.move_uci(e["move_b"][best]) + ")"
-    assert lines[-1] == "bestmove " + want, (lines, want)
+    assert lines[-1].split(" ponder ")[0] == "bestmove " + want, (lines, want)
     m = re.match(r"info depth (\d+) score (cp|mate) (-?\d+) nodes (\d+) nps (\d+) hashfull 0 tbhits 0 time (\d+) pv (\(.*\))$", lines[0])
-    assert m and int(m.group(4)) == s.info()["nodes"] and m.group(7) == want, lines[0]
+    assert m and int(m.group(4)) == s.info()["nodes"] and m.group(7).split(" ")[0] == want, lines[0]
+    # the principal variation (extract_pv_from_child, agent.cc:1218-1290) and the ponder move (agent.cc:1054-1113)
+    pv = s.pv_lines(1, 20)[0]
+    assert pv["child"] == best and m.group(7) == " ".join(_joint(a, bb) for a, bb in pv["moves"]), (lines[0], pv)
+    if len(pv["moves"]) >= 2:
+        assert lines[-1] == "bestmove " + want + " ponder " + _joint(*pv["moves"][1])
     if m.group(2) == "cp":
         import math
         assert int(m.group(3)) == int(180.0 * math.tan(1.56 * float(e["q"][best])))          # format_uci_score, agent.cc:75
     u.close()
+
+
+@pytest.mark.parametrize("moves,nodes,multipv", [([], 400, 4), (["1e2e4", "1e7e5", "2d2d4", "2d7d5"], 800, 3), (["1e2e4", "2e2e4"], 96, 500)])
+def test_go_multipv_lines_match_oracle(hm, moves, nodes, multipv):
+    """`setoption MultiPV n`: n final info lines (fewer when the root has fewer children), children by visit count with the solver-aware
+    best move first (agent.cc:917-965), each with score, PV and `multipv k`; Ponder false drops the ponder move (agent.cc:993-999)"""
+    import math
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=2000)
+    assert u.command(f"setoption name MultiPV value {multipv}")[0] == f"info string MultiPV set to {multipv}\n"
+    assert u.command("setoption name Ponder value false")[0] == "info string Ponder set to false\n"
+    u.command("position startpos" + (" moves " + " ".join(moves) if moves else ""))
+    text, _ = u.command(f"go nodes {nodes}")
+    lines = text.strip().split("\n")
+    s = O.Search(1, 1)
+    assert s.run(_oracle_board(None, moves), 0, False, nodes)
+    want = s.pv_lines(multipv, 20)
+    info = [l for l in lines if l.startswith("info depth")]
+    assert len(info) == len(want) == min(multipv, len(s.edges()["visits"])) and len(want) >= 3
+    assert want[0]["child"] == s.best_move()
+    for k, (line, w) in enumerate(zip(info, want)):
+        m = re.match(r"info depth (\d+) multipv (\d+) score (cp|mate) (-?\d+) nodes (\d+) nps \d+ hashfull 0 tbhits 0 time \d+ pv (\(.*\))$", line)
+        assert m and int(m.group(2)) == k + 1 and int(m.group(5)) == s.info()["nodes"], line
+        assert m.group(6) == " ".join(_joint(a, b) for a, b in w["moves"]), (k, line, w)
+        if m.group(3) == "cp":
+            assert int(m.group(4)) == int(180.0 * math.tan(1.56 * w["q"])), (line, w)
+    assert any(len(w["moves"]) >= 3 for w in want)                    # the walk goes below the root's children
+    assert lines[-1] == "bestmove " + _joint(*want[0]["moves"][0])   # Ponder false: no ponder move
+    u.close()
+
+
+def test_policy_command_matches_oracle(hm):
+    """UCI::policy (uci.cc:306-393): value / WDL / plies of one forward of the position as the team sees it, and per board the legal
+    moves + pass with normalised policy, most probable first; the FEN strings are Board::fen's"""
+    moves = ["1e2e4", "2d2d4", "2d7d5", "1d7d5", "1e4d5", "1d8d5", "2e2e4", "2d5e4"]          # captures: pockets are not empty
+    b = _oracle_board(None, moves)
+    normal, drop = O.policy_tables("ora")
+    for team, mode in (("white", "go"), ("black", "sit")):
+        u = hm.Uci(DeviceHashNet(hm), max_nodes=500)
+        u.command(f"setoption name Team value {team}")
+        u.command(f"setoption name Mode value {mode}")
+        u.command("position startpos moves " + " ".join(moves))
+        text, _ = u.command("policy")
+        t = 0 if team == "white" else 1
+        planes = O.planes(b.compact(t, mode == "sit"))
+        v, pa, pb, w, ml = O.hash_evaluator(planes)
+        f = lambda x: x.view(np.float16).astype(np.float32)
+        lines = text.split("\n")
+        assert lines[0] == "Value: %g" % f(v)[0]
+        e = np.exp(f(w)[0] - f(w)[0].max()).astype(np.float32)
+        got = [float(x) for x in lines[1].split()[1:]]
+        assert lines[1].startswith("WDL: ") and np.allclose(got, [e[2] / e.sum(), e[1] / e.sum(), e[0] / e.sum()], rtol=2e-5)
+        assert lines[2] == "Predicted plies to end: %g" % (f(ml)[0] * np.float32(100.0)) and lines[3] == ""
+        at = 4
+        for bd, pol in ((0, pa), (1, pb)):
+            assert lines[at] == f"Board {'AB'[bd]} ({b.fen(bd)}):", lines[at]
+            at += 1
+            stm = int(b.compact(0, False)["pos"][0, bd]["stm"])
+            if stm != (t if bd == 0 else t ^ 1):
+                assert lines[at] == "  (not our turn)"
+                at += 1
+            else:
+                legal = [int(m) for m in b.legal_moves(bd)] + [0]
+                logit = []
+                for m in legal:
+                    kind, promo = (m >> 12) & 15, (m >> 16) & 63
+                    if m == 0:
+                        idx = 0
+                    elif kind == 4:
+                        idx = drop[stm, m & 63, promo]
+                    else:
+                        idx = normal[stm, (m >> 6) & 63, m & 63, 1 if (kind == 3 and promo == 2) else 0]
+                    logit.append(f(pol)[0][idx] if idx >= 0 else -np.inf)
+                logit = np.array(logit, np.float32)
+                pr = np.exp(logit - logit.max()).astype(np.float32)
+                pr = pr / pr.sum()
+                rows = lines[at:at + len(legal)]
+                at += len(legal)
+                got = {r.strip().split(": ")[0]: float(r.split(": ")[1]) for r in rows}
+                assert set(got) == {O.move_uci(m) for m in legal} and "pass" in got
+                for m, p_ in zip(legal, pr):
+                    assert abs(got[O.move_uci(m)] - p_) <= 2e-5 * max(p_, 1e-3), (O.move_uci(m), got[O.move_uci(m)], p_)
+                vals = [float(r.split(": ")[1]) for r in rows]
+                assert vals == sorted(vals, reverse=True)
+            if bd == 0:
+                assert lines[at] == ""
+                at += 1
+        assert lines[at:] == [""]
+        u.close()
 
 
 def test_go_without_a_board_on_turn_says_none(hm):
@@ -132,7 +229,7 @@ def test_go_movetime_returns_a_legal_best_move(hm):
     u.command("position startpos moves 1e2e4 2e2e4")
     text, _ = u.command("go movetime 60")
     last = text.strip().split("\n")[-1]
-    m = re.match(r"bestmove \((\S+),(\S+)\)$", last)
+    m = re.match(r"bestmove \((\S+),(\S+)\)(?: ponder \(\S+,\S+\))?$", last)
     assert m, text
     b = _oracle_board(None, ["1e2e4", "2e2e4"])
     for bd, mv in ((0, m.group(1)), (1, m.group(2))):
