@@ -14,17 +14,21 @@
 // PWExponentPermille, Transpositions} (Hash is accepted and reported as the reference does), policy (uci.cc:306-393), quit.
 // The final `info` lines carry MultiPV principal variations (agent.cc:917-965, 1218-1290; walked on the device by hm_sp_pv_lines)
 // and `bestmove` carries the ponder move (agent.cc:1054-1113) when Ponder is on.
-// Not built (documented in DESIGN.md): `go ponder` / ponderhit (a search that runs until told to stop) and tree reuse between moves.  `go movetime` follows the reference's polling loop (early exit on a
-// solved root / forced mate, early stopping on an insurmountable visit lead, time extension).  A search is synchronous: the command returns when `bestmove` has been printed.
+// `go ponder` runs on a worker thread until `ponderhit` (then its budget applies, clock restarted) or `stop`; every other `go` is
+// synchronous.  Not built (documented in DESIGN.md): tree reuse between moves (Agent::try_reuse_tree, agent.cc:1345-1451).  `go movetime` follows the reference's polling loop (early exit on a
+// solved root / forced mate, early stopping on an insurmountable visit lead, time extension).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hivemind_amd.h"
@@ -234,7 +238,10 @@ struct hm_uci {
     uint32_t* d_counts = nullptr;
     hm_board* d_board = nullptr;      // `policy`: the position handed to the plane encoder
     hipStream_t sN = nullptr;
-    std::string out;
+    std::string out;                  // pending output text (guarded by mu: a ponder search appends from its thread)
+    std::mutex mu;
+    std::thread worker;               // `go ponder` runs here
+    std::atomic<bool> pondering{false}, stopReq{false}, busy{false};
 };
 
 static int uci_rebuild_engine(hm_uci* u) {
@@ -312,24 +319,25 @@ static std::string uci_score(int childType, int childEndInPly, float q) {   // f
     return "score cp " + std::to_string(static_cast<int>(180.0f * std::tan(1.56f * q)));
 }
 
-static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Agent::run_search (agent.cc:421-558, 898-1002)
-    std::string token;
-    int moveTime = 0;
-    size_t nodes = 0;
-    while (is >> token) {
-        if (token == "movetime") is >> moveTime;
-        else if (token == "nodes") is >> nodes;
-    }
-    if (nodes == 0 && moveTime <= 0) moveTime = 1000;                               // "Default to 1 second if nothing specified"
+struct GoParams { int moveTime = 0; size_t nodes = 0; bool ponder = false; };
+
+// Agent::run_search (agent.cc:421-558, 561-713, 898-1002) for one `go`: the lockstep loop of the single game slot, the budget rules
+// and the final info / bestmove lines, appended to `out`.  A ponder search (SearchOptions::isPonder, agent.h:31) ignores its budget
+// until `ponderhit` clears hm_uci::pondering; the clock restarts there (SearchInfo, searchinfo.h:39) and the budget applies from then
+// on.  `stop` (hm_uci::stopReq) ends either kind at the next iteration.  bestmove is never printed while still pondering.
+static void uci_search(hm_uci* u, GoParams gp, std::string& out) {
+    int moveTime = gp.moveTime;
+    const size_t nodes = gp.nodes;
     const uint8_t team = (uint8_t)u->team, adv = u->sit ? 1 : 0, one = 1;
-    if (hm_sp_set_side(u->sp, &team, &adv)) { u->out += "bestmove (none)\n"; return; }
-    const int target = nodes > 0 ? (int)std::min<size_t>(nodes, (size_t)u->maxNodes) : u->maxNodes;
+    if (hm_sp_set_side(u->sp, &team, &adv)) { out += "bestmove (none)\n"; return; }
+    // a ponder search runs on until told otherwise: its device-side node target is the pool size, the node budget is applied by the host
+    const int target = (nodes > 0 && !gp.ponder) ? (int)std::min<size_t>(nodes, (size_t)u->maxNodes) : u->maxNodes;
     const uint64_t seed = 0;
-    const auto t0 = std::chrono::steady_clock::now();
+    auto t0 = std::chrono::steady_clock::now();
     auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    if (hm_sp_begin_search(u->sp, &target, &seed, 0.0f, 0.0f, &one)) { u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
+    if (hm_sp_begin_search(u->sp, &target, &seed, 0.0f, 0.0f, &one)) { out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
     int active = 1, which = 0, iters = 0;
-    bool stopped = false;
+    bool stopped = false, wasPondering = gp.ponder;
     void* heads[5] = {u->io.value, u->io.pi_a, u->io.pi_b, u->io.wdl, u->io.moves_left};
     hm_time_manager tm;
     tm.moveTimeMs = moveTime; tm.effectiveMs = moveTime;
@@ -342,10 +350,29 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
         if (!rc) rc = u->net ? hm_net_forward(u->net, u->io.planes[which], 8, heads[0], heads[1], heads[2], heads[3], heads[4], nullptr)
                              : u->fn(u->user, which, 8);
         if (!rc) rc = hm_sp_process(u->sp, heads[0], heads[1], heads[2], heads[3], heads[4], &active, nullptr);
-        if (rc) { u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
+        if (rc) { out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
         which = 1 - which;
         ++iters;
-        if (!stopped && nodes == 0 && active > 0) {
+        if (!stopped && u->stopReq.load(std::memory_order_acquire)) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }
+        const bool pondering = u->pondering.load(std::memory_order_acquire);
+        if (wasPondering && !pondering) {                   // ponderhit: the turn starts now
+            wasPondering = false;
+            t0 = std::chrono::steady_clock::now();
+            lastPoll = 0.0;
+        }
+        if (!stopped && !pondering && gp.ponder && nodes > 0 && active > 0) {
+            // node budget of a search that started as a ponder search (agent.cc:573: nodes < target once isPondering_ is cleared)
+            const double now = elapsed_ms();
+            if (now - lastPoll >= 1.0 || lastPoll == 0.0) {
+                lastPoll = now;
+                int count = 0;
+                if (!hm_sp_root_stats(u->sp, &count, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pinfo.data(), E0) && (size_t)pinfo[1] >= nodes) {
+                    (void)hm_sp_stop(u->sp, nullptr, nullptr);
+                    stopped = true;
+                }
+            }
+        }
+        if (!stopped && !pondering && nodes == 0 && active > 0) {
             // the reference polls every 5 ms (agent.cc:562, 577-580): early exit on a solved root / forced mate, early stopping
             // on an insurmountable visit lead, time extension on a falling evaluation or a late change of the best move
             const double now = elapsed_ms();
@@ -360,22 +387,24 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
                     for (int i = 0; i < count; ++i) { ptype[i] = 0; pend[i] = 0; }
                     if (pinfo[12] >= 0 && pinfo[12] < count) { ptype[pinfo[12]] = pinfo[14]; pend[pinfo[12]] = pinfo[15]; }
                     stop = tm_poll(tm, now, pinfo[1], count, pv.data(), pq.data(), pinfo[6] > 0 ? pinfo[6] : 0, ptype.data(), pend.data());
-                    u->out += tm.log; tm.log.clear();
+                    out += tm.log; tm.log.clear();
                 }
             }
             if (stop) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }
         }
     }
+    // the pool is exhausted but the GUI has not answered the ponder search yet: hold the result (UCI: no bestmove while pondering)
+    while (u->pondering.load(std::memory_order_acquire) && !u->stopReq.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     const int E = hm_sp_max_edges(u->sp);
     std::vector<hm_move> mA(E), mB(E);
     std::vector<int> visits(E), info(HM_SP_INFO_INTS);
     std::vector<float> q(E);
     int count = 0;
     float rootQ = 0.0f;
-    if (hm_sp_root_stats(u->sp, &count, mA.data(), mB.data(), visits.data(), q.data(), nullptr, &rootQ, info.data(), E)) { u->out += "bestmove (none)\n"; return; }
+    if (hm_sp_root_stats(u->sp, &count, mA.data(), mB.data(), visits.data(), q.data(), nullptr, &rootQ, info.data(), E)) { out += "bestmove (none)\n"; return; }
     const double ms = elapsed_ms();
     const int nodesDone = info[1], depth = info[9], best = info[12];
-    if (count <= 0 || best < 0 || best >= count) { u->out += "bestmove (none)\n"; return; }
+    if (count <= 0 || best < 0 || best >= count) { out += "bestmove (none)\n"; return; }
     const std::string bestText = "(" + uci_text(mA[best]) + "," + uci_text(mB[best]) + ")";
     const int nps = ms > 0 ? (int)(nodesDone * 1000.0 / ms) : 0;
     // final info lines (agent.cc:917-965): root children by visit count (the reference's std::sort and comparator), the solver-aware
@@ -393,7 +422,7 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
     std::vector<hm_move> pvMoves((size_t)numPVs * PV_DEPTH * 2);
     for (int k = 0; k < numPVs; ++k) childIdx[k] = (int)order[k];
     if (hm_sp_pv_lines(u->sp, 0, numPVs, childIdx.data(), PV_DEPTH, pvMoves.data(), lens.data(), ctype.data(), cend.data())) {
-        u->out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n";
+        out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n";
         return;
     }
     auto joint_text = [&](int k, int d) { const hm_move* m = &pvMoves[((size_t)k * PV_DEPTH + d) * 2]; return "(" + uci_text(m[0]) + "," + uci_text(m[1]) + ")"; };
@@ -403,14 +432,55 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231 + Ag
         s += " " + uci_score(ctype[k], cend[k], q[childIdx[k]]) + " nodes " + std::to_string(nodesDone) + " nps " + std::to_string(nps)
              + " hashfull 0 tbhits 0 time " + std::to_string((int)ms);
         for (int d = 0; d < lens[k]; ++d) s += (d == 0 ? " pv " : " ") + joint_text(k, d);
-        u->out += s + "\n";
+        out += s + "\n";
     }
     char line[256];
     std::snprintf(line, sizeof line, "info string rejected selection attempts %d (same batch %d, pending evaluation %d)\n", info[3] + info[4], info[3], info[4]);
-    u->out += line;
+    out += line;
     // extract_ponder_move (agent.cc:1054-1113): the best child's own best reply = the second joint action of line 1
-    if (u->ponder && numPVs > 0 && lens[0] >= 2) u->out += "bestmove " + bestText + " ponder " + joint_text(0, 1) + "\n";
-    else u->out += "bestmove " + bestText + "\n";
+    if (u->ponder && numPVs > 0 && lens[0] >= 2) out += "bestmove " + bestText + " ponder " + joint_text(0, 1) + "\n";
+    else out += "bestmove " + bestText + "\n";
+}
+
+// UCI::stop (uci.cc:30-50): end a running search and wait for its output
+static void uci_stop(hm_uci* u) {
+    if (!u->worker.joinable()) return;
+    u->stopReq.store(true, std::memory_order_release);
+    u->worker.join();
+    u->stopReq.store(false, std::memory_order_release);
+    u->pondering.store(false, std::memory_order_release);
+}
+
+static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231
+    std::string token;
+    GoParams gp;
+    while (is >> token) {
+        if (token == "ponder") gp.ponder = true;
+        else if (token == "movetime") is >> gp.moveTime;
+        else if (token == "nodes") is >> gp.nodes;
+    }
+    uci_stop(u);
+    if (gp.nodes == 0 && gp.moveTime <= 0) gp.moveTime = 1000;                      // "Default to 1 second if nothing specified"
+    if (!gp.ponder) {                                        // the command returns when bestmove has been printed
+        std::string text;
+        uci_search(u, gp, text);
+        std::lock_guard<std::mutex> lock(u->mu);
+        u->out += text;
+        return;
+    }
+    // ponder search: runs on a worker thread until `ponderhit` (then its budget applies) or `stop`; the text is fetched with later
+    // commands (an empty line polls)
+    u->pondering.store(true, std::memory_order_release);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    u->busy.store(true, std::memory_order_release);
+    u->worker = std::thread([u, gp, dev]() {
+        (void)hipSetDevice(dev);
+        std::string text;
+        uci_search(u, gp, text);
+        { std::lock_guard<std::mutex> lock(u->mu); u->out += text; }
+        u->busy.store(false, std::memory_order_release);
+    });
 }
 
 static float half_to_float(uint16_t h) {
@@ -547,8 +617,9 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
     std::string token;
     is >> std::skipws >> token;
     bool quit = false;
+    auto say = [&](const char* s) { std::lock_guard<std::mutex> lock(u->mu); u->out += s; };
     if (token == "uci") {   // send_uci_response, uci.cc:298-317
-        u->out += "id name hivemind\nid author aminwoo\n\n"
+        say("id name hivemind\nid author aminwoo\n\n"
                   "option name Hash type spin default 16 min 1 max 33554432\n"
                   "option name MultiPV type spin default 1 min 1 max 500\n"
                   "option name Ponder type check default true\n"
@@ -560,21 +631,26 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
                   "option name Team type combo default white var white var black\n"
                   "option name Mode type combo default go var sit var go\n"
                   "info string HIP engines 1 search workers 1 (one wavefront pipeline per game)\n"
-                  "uciok\n";
-    } else if (token == "isready") u->out += "readyok\n";
+                  "uciok\n");
+    } else if (token == "isready") say("readyok\n");
     else if (token == "go") uci_go(u, is);
-    else if (token == "setoption") uci_setoption(u, is);
-    else if (token == "position") uci_position(u, is);
-    else if (token == "ucinewgame") { hm_board b; hm_board_startpos(&b); (void)uci_set_position(u, b); }   // new_game: search state is per `go` here
-    else if (token == "policy") uci_policy(u);
-    else if (token == "stop" || token == "ponderhit") {}          // searches are synchronous: nothing is running between commands
-    else if (token == "quit") quit = true;
+    else if (token == "ponderhit") u->pondering.store(false, std::memory_order_release);      // Agent::ponderhit (agent.cc:1304-1310)
+    else if (token == "stop") uci_stop(u);
+    else if (token == "setoption") { uci_stop(u); uci_setoption(u, is); }
+    else if (token == "position") { uci_stop(u); uci_position(u, is); }
+    else if (token == "ucinewgame") { uci_stop(u); hm_board b; hm_board_startpos(&b); (void)uci_set_position(u, b); }   // new_game: search state is per `go` here
+    else if (token == "policy") { uci_stop(u); uci_policy(u); }
+    else if (token == "quit") { uci_stop(u); quit = true; }
+    std::lock_guard<std::mutex> lock(u->mu);
     if ((int64_t)u->out.size() + 1 > cap || !out) return quit ? HM_UCI_QUIT : -(int64_t)u->out.size() - 1;
     std::memcpy(out, u->out.c_str(), u->out.size() + 1);
     const int64_t n = (int64_t)u->out.size();
     u->out.clear();
     return quit ? HM_UCI_QUIT : n;
 }
+
+// 1 while a `go ponder` search is running on its worker thread (its text arrives with later commands; an empty line polls).
+int hm_uci_busy(hm_uci* u) { return u && u->busy.load(std::memory_order_acquire) ? 1 : 0; }
 
 // Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text
 // length, or -(needed size) when cap is too small.
@@ -596,6 +672,7 @@ int hm_uci_board(hm_uci* u, hm_board* out) {
 
 int hm_uci_destroy(hm_uci* u) {
     if (!u) return 0;
+    uci_stop(u);
     if (u->sp) hm_sp_destroy(u->sp);
     if (u->d_pos) (void)hipFree(u->d_pos);
     if (u->d_moves) (void)hipFree(u->d_moves);

@@ -17,6 +17,7 @@ _SIGS = {
     "hm_uci_command": (C.c_int64, [_vp, C.c_char_p, _vp, C.c_int64]),
     "hm_uci_board": (_i, [_vp, _vp]),
     "hm_uci_destroy": (_i, [_vp]),
+    "hm_uci_busy": (_i, [_vp]),
     "hm_board_fen": (_i, [_vp, _i, C.c_char_p, _i]),
     "hm_insurmountable_visit_lead": (_i, [C.c_float, C.c_float, C.c_float]),
     "hm_time_manager_create": (_vp, [_i]),
@@ -75,8 +76,16 @@ class Uci:
         """-> (output text, quit flag)"""
         n = lib.hm_uci_command(self.h, line.encode(), self._buf, len(self._buf))
         if self._error is not None:
-            raise self._error
+            err, self._error = self._error, None
+            raise err
+        if n < 0 and n != UCI_QUIT:                              # the text did not fit: the command has run, fetch with an empty line
+            self._buf = C.create_string_buffer(int(-n) + 1)
+            n = lib.hm_uci_command(self.h, b"", self._buf, len(self._buf))
         return self._buf.value.decode() if n != 0 else "", n == UCI_QUIT
+
+    def busy(self) -> bool:
+        """a `go ponder` search is still running (poll its text with command(""))"""
+        return bool(lib.hm_uci_busy(self.h))
 
     def board(self):
         import numpy as np
@@ -108,13 +117,25 @@ def main(argv=None):
     torch.manual_seed(0)
     model = N.load_checkpoint(a.checkpoint) if a.checkpoint else (N.rise_v3_small() if a.model == "small" else N.rise_v33())
     uci = Uci(N.FusedNet(model), a.max_nodes)
-    for line in sys.stdin:
-        text, quit_ = uci.command(line.strip())
+    import select
+
+    def emit(text):
         if text:
             sys.stdout.write(text)
             sys.stdout.flush()
+    while True:
+        # a ponder search prints when it ends (after ponderhit / stop): poll its text between input lines
+        if uci.busy() and not select.select([sys.stdin], [], [], 0.005)[0]:
+            emit(uci.command("")[0])
+            continue
+        line = sys.stdin.readline()
+        if not line:
+            break
+        text, quit_ = uci.command(line.strip())
+        emit(text)
         if quit_:
             break
+    emit(uci.command("")[0])
     uci.close()
 
 

@@ -489,7 +489,8 @@ int hm_move_uci(hm_move move, char* out, int cap);
 /* reference's early exit / early stopping / time extension rules; final    */
 /* `info` lines with MultiPV principal variations (agent.cc:917-965,        */
 /* 1218-1290) and `bestmove ... ponder ...` (agent.cc:1054-1113).           */
-/* Not built: `go ponder` / ponderhit, tree reuse between moves.            */
+/* `go ponder ...` searches on a worker thread until `ponderhit` (then the  */
+/* budget applies) or `stop`.  Not built: tree reuse between moves.         */
 /* ================================================================== */
 typedef struct hm_uci hm_uci;
 #define HM_UCI_QUIT (-1000000)
@@ -501,6 +502,8 @@ int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* 
 int64_t hm_uci_command(hm_uci* uci, const char* line, char* out, int64_t cap);
 /* The current game position (after the last `position`), team / time_adv = the Team / Mode options. */
 int hm_uci_board(hm_uci* uci, hm_board* out);
+/* 1 while a `go ponder` search is running (its text arrives with later commands; an empty line polls). */
+int hm_uci_busy(hm_uci* uci);
 /* Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text
  * length, or -(needed size) when cap is too small. */
 int hm_board_fen(const hm_board* board_pair, int board, char* out, int cap);

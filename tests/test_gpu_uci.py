@@ -209,6 +209,58 @@ def test_policy_command_matches_oracle(hm):
         u.close()
 
 
+def _wait_for_bestmove(u, limit_s=20.0):
+    import time
+    text, t0 = "", time.time()
+    while "bestmove" not in text and time.time() - t0 < limit_s:
+        text += u.command("")[0]
+        time.sleep(0.002)
+    return text
+
+
+def test_go_ponder_runs_until_ponderhit_or_stop(hm):
+    """`go ponder` (uci.cc:150-151, agent.h:31): the search ignores its budget and prints nothing until `ponderhit` (then the budget
+    applies: nodes -> at least that many, movetime -> the clock starts at ponderhit) or `stop`"""
+    import time
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=60000)
+    u.command("position startpos moves 1e2e4 2d2d4")
+    # node budget: far more than 64 nodes are searched while pondering; after ponderhit the budget is already met
+    assert u.command("go ponder nodes 64") == ("", False) and u.busy()
+    time.sleep(0.25)
+    assert u.command("")[0] == "" and u.busy()                              # still pondering: nothing printed
+    assert u.command("ponderhit") [1] is False
+    text = _wait_for_bestmove(u)
+    info = [l for l in text.split("\n") if l.startswith("info depth")][0]
+    nodes = int(re.search(r" nodes (\d+) ", info).group(1))
+    assert nodes > 64 and text.strip().split("\n")[-1].startswith("bestmove (") and not u.busy()
+    # stop: ends the ponder search, bestmove follows at once; the answer is a legal joint action
+    u.command("go ponder movetime 100000")
+    time.sleep(0.1)
+    text, _ = u.command("stop")
+    last = text.strip().split("\n")[-1]
+    m = re.match(r"bestmove \((\S+),(\S+)\)", last)
+    assert m and not u.busy(), text
+    b = _oracle_board(None, ["1e2e4", "2d2d4"])
+    for bd, mv in ((0, m.group(1)), (1, m.group(2))):
+        assert mv == "pass" or b.find_move(bd, mv) != 0, (bd, mv)
+    # movetime after ponderhit: the clock starts at ponderhit, not at `go`
+    u.command("go ponder movetime 150")
+    time.sleep(0.3)
+    assert u.busy() and u.command("")[0] == ""
+    t0 = time.time()
+    u.command("ponderhit")
+    text = _wait_for_bestmove(u)
+    dt = (time.time() - t0) * 1e3
+    info = [l for l in text.split("\n") if l.startswith("info depth")][0]
+    assert 100 <= int(re.search(r" time (\d+) ", info).group(1)) < 1500 and dt >= 100, (info, dt)
+    # a new command while pondering stops the search first (UCI::go / setoption call stop(), uci.cc:160, 217)
+    u.command("go ponder nodes 100")
+    text, _ = u.command("position startpos")
+    assert "bestmove" in text and not u.busy()
+    assert u.command("go nodes 80")[0].strip().split("\n")[-1].startswith("bestmove (")
+    u.close()
+
+
 def test_go_without_a_board_on_turn_says_none(hm):
     """neither of the team's boards is on turn and sitting out is not allowed: Agent::run_search prints `bestmove (none)`
     (agent.cc:438-450); the CPU restatement refuses the search as well"""
