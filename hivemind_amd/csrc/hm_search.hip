@@ -127,7 +127,10 @@ struct Game {
     int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
     int listWords;                      // leaf move-list words written by the helper wave (traffic accounting)
     int live;                           // slot holds a game (set by k_set_games); dead slots are skipped by every kernel
-    int pwSel;                          // progressive-widening profile of the side searching now: 0 = the engine's tables, 1 = the alternate pair (hm_sp_set_pw_profiles)
+    int pwSel;                          // progressive-widening profile of the side searching now: 0 = the engine's tables, 1 = the alternate pair (hm_sp_set_pw_profiles)    // tree reuse between searches (Agent::try_reuse_tree, agent.cc:1345-1371)
+    int lastRootP1;                     // 1 + root of this slot's previous search, whose tree is still in the pool (0 = none: reset_search_state)
+    int reuseMode;                      // 0 = every search starts from an empty pool; 1 = reuse when the node budget still fits; 2 = and shrink the budget to what fits
+    int reusedVisits;                   // visits of the recovered root, -1 = fresh root
 };
 
 struct Params {          // device-visible configuration + pool geometry
@@ -1715,6 +1718,90 @@ __global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params p
     PROF_FLUSH();
 }
 
+// Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
+// solver-aware, Q-veto, Q-weighting), the most-visited fallback and the index clamp.  One lane; the root has few edges.
+__device__ inline int best_move_index(const G& s, const Node& r, float qVetoDelta, float qValueWeight) {
+    if (!(r.flags & F_EXPANDED) || r.expanded <= 0) return -1;
+    const Edge* e = edges_of(s, r);
+    const int n = r.expanded;
+    int best = -1;
+    bool decided = false;
+    if (r.type == T_WIN) {
+        int shortest = 0x7fffffff;
+        for (int i = 0; i < r.cntTypes; ++i)
+            if (e[i].ctype == T_LOSS && s.nodes[e[i].child].endInPly < shortest) { shortest = s.nodes[e[i].child].endInPly; best = i; }
+        decided = best >= 0;
+    }
+    if (!decided && r.type == T_LOSS) {
+        best = 0;
+        int longest = 0;
+        for (int i = 0; i < n; ++i) { const int ep = s.nodes[e[i].child].endInPly; if (ep > longest) { longest = ep; best = i; } }
+        decided = true;
+    }
+    if (!decided) {
+        bool hasNonLosing = false;
+        for (int i = 0; i < n; ++i) hasNonLosing |= s.nodes[e[i].child].type != T_WIN;
+        auto eligible = [&](int i) { return !hasNonLosing || s.nodes[e[i].child].type != T_WIN; };
+        int first = 0;
+        while (first < n && !eligible(first)) ++first;
+        if (first == n) best = -1;
+        else {
+            int bestVisitIdx = first, maxVisits = e[first].visits, secondVisitIdx = -1;
+            for (int i = first + 1; i < n; ++i) {
+                if (!eligible(i)) continue;
+                if (e[i].visits > maxVisits) { secondVisitIdx = bestVisitIdx; maxVisits = e[i].visits; bestVisitIdx = i; }
+                else if (secondVisitIdx < 0 || e[i].visits > e[secondVisitIdx].visits) secondVisitIdx = i;
+            }
+            int bestQIdx = first;
+            float bestQ = e[first].q;
+            for (int i = first + 1; i < n; ++i) { if (!eligible(i)) continue; if (e[i].q > bestQ) { bestQ = e[i].q; bestQIdx = i; } }
+            best = bestVisitIdx;
+            bool done = false;
+            if (qVetoDelta > 0.0f && bestQIdx != bestVisitIdx && e[bestQIdx].q > e[bestVisitIdx].q + qVetoDelta && e[bestQIdx].visits > 1) { best = bestQIdx; done = true; }
+            if (!done && qValueWeight > 0.0f && secondVisitIdx >= 0 && e[secondVisitIdx].q > e[bestVisitIdx].q) {
+                const float qDifference = e[secondVisitIdx].q - e[bestVisitIdx].q;
+                const float adjusted = (float)e[secondVisitIdx].visits + qDifference * qValueWeight * (float)e[bestVisitIdx].visits;
+                if (adjusted > (float)e[bestVisitIdx].visits) best = secondVisitIdx;
+            }
+        }
+    }
+    if (best < 0) {                                       // agent.cc:872-880
+        int maxVisits = 0;
+        for (int i = 0; i < n; ++i) if (e[i].visits > maxVisits) { maxVisits = e[i].visits; best = i; }
+    }
+    if (best < 0 || best >= n) best = 0;                  // agent.cc:882-886
+    return best;
+}
+
+// Agent::store_next_root_candidates + try_reuse_tree (agent.cc:1345-1451) in one step, at the start of the next search: the
+// candidates are the previous root's selected child (final-move rule) and every reply generated below it, in that order; the
+// first whose hash, side to play and position equal the new root's is taken.  The reference compares hash and a FEN signature of
+// both boards; here the cached NodePos (both positions incl. pockets, castling, ep, clocks, and the history chain) is compared
+// word for word, which is the same condition.  A candidate that was generated but never reached has no position record and is
+// not taken (the reference would adopt its empty node, which searches exactly like a fresh root).
+__device__ inline int find_reusable_root(const G& s, int prevRoot, u64 hash, int team) {
+    const Node& r = s.nodes[prevRoot];
+    const int b = best_move_index(s, r, s.prm->qVetoDelta, s.prm->qValueWeight);
+    if (b < 0) return -1;
+    auto matches = [&](int id) {
+        const Node& nd = s.nodes[id];
+        if (nd.hash != hash || (int)nd.team != team || !nd.posOff) return false;
+        const NodePos* np = nodepos_of(s, nd);
+        const u64* a = reinterpret_cast<const u64*>(np->pos);
+        const u64* c = reinterpret_cast<const u64*>(s.g->pos);
+        bool same = np->hlen[0] == s.g->hlen[0] && np->hlen[1] == s.g->hlen[1] && np->prefix[0] == s.g->prefix[0] && np->prefix[1] == s.g->prefix[1];
+        for (int i = 0; i < (int)(2 * sizeof(hm_pos) / 8); ++i) same = same && a[i] == c[i];
+        return same;
+    };
+    const int c = edges_of(s, r)[b].child;
+    if (matches(c)) return c;
+    const Node& cn = s.nodes[c];
+    if (!(cn.flags & F_EXPANDED)) return -1;
+    const Edge* e = edges_of(s, cn);
+    for (int i = 0; i < cn.expanded; ++i) if (matches(e[i].child)) return e[i].child;
+    return -1;
+}
+
 // Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
 __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* targetNodes, const u64* noiseSeeds, float alpha, float eps, const uint8_t* searchMask, u64* rootHashOut) {
     __shared__ RulesTab s_rt;
@@ -1728,7 +1815,10 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     for (int i = lane; i < prm.ttCap; i += 64) s.ttVals[i] = -1;
     wave_fence();
     Game& gm = *s.g;
-    gm.nodeCount = 0; gm.arenaTop = 1; gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
+    // The pool itself is reset below, once it is known that the previous search's tree is not carried over (tree reuse).
+    const int prevRoot = gm.reuseMode ? gm.lastRootP1 - 1 : -1;
+    gm.reusedVisits = -1;
+    gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
     gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
     gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
     gm.nodesVisited = gm.edgesScanned = 0; gm.fresh = 0; gm.listWords = 0;
@@ -1860,6 +1950,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
             }
         }
         if (found) {   // agent.cc:458-499: trivial proven tree
+            gm.nodeCount = 0; gm.arenaTop = 1;
             const int root = node_alloc(s, team, 0);
             const int child = node_alloc(s, team ^ 1, 1);
             Node rn = s.nodes[root];
@@ -1873,73 +1964,39 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
             rn.type = T_WIN; rn.valueSum = 1.0f * (float)(rn.visits + 1); rn.endInPly = 1;
             s.nodes[root] = rn;
             gm.root = root;
+            gm.lastRootP1 = root + 1;
             gm.status = ST_DONE;
             return;
         }
     }
-    const int root = node_alloc(s, team, 0);
-    if (root < 0) { gm.status = ST_ERROR; return; }
-    s.nodes[root].hash = rootHash;
-    path_reset(s, p);                                          // the mate scan left p.jb untouched, but be explicit
-    if (!path_store(s, s_rt, p, root)) { gm.status = ST_ERROR; return; }   // the root's position record (every descent starts from it)
+    // Tree reuse (agent.cc:507-525): the previous search's selected child or one of the replies below it becomes the root, with
+    // everything searched beneath it, when it is this very position (hash, side, both boards, history) and the pool still has
+    // room for the node budget behind the nodes it already holds.
+    int root = (prevRoot >= 0 && prevRoot < gm.nodeCount) ? find_reusable_root(s, prevRoot, rootHash, team) : -1;
+    if (root >= 0) {
+        const int fitNodes = (prm.nodeCap - 64 - gm.nodeCount) / 3 - 2 * BATCH;
+        const long long fitArena = ((long long)prm.arenaCap - (long long)gm.arenaTop - 8192) / 768 - 2 * BATCH;
+        const int fit = (int)(fitArena < (long long)fitNodes ? fitArena : (long long)fitNodes);
+        if (fit >= gm.targetNodes) {}
+        else if (gm.reuseMode == 2 && fit >= gm.targetNodes / 2) gm.targetNodes = fit;
+        else root = -1;
+    }
+    if (root >= 0) {
+        Node& rn = s.nodes[root];
+        rn.hash = rootHash; rn.depth = 0;
+        gm.reusedVisits = rn.visits;
+    } else {
+        gm.nodeCount = 0; gm.arenaTop = 1;
+        root = node_alloc(s, team, 0);
+        if (root < 0) { gm.status = ST_ERROR; return; }
+        s.nodes[root].hash = rootHash;
+        path_reset(s, p);                                          // the mate scan left p.jb untouched, but be explicit
+        if (!path_store(s, s_rt, p, root)) { gm.status = ST_ERROR; return; }   // the root's position record (every descent starts from it)
+    }
     gm.root = root;
+    gm.lastRootP1 = root + 1;
     if (prm.enableTranspositions) tt_insert_or_get(s, rootHash, root);
     gm.status = ST_SEARCHING;
-}
-
-// Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
-// solver-aware, Q-veto, Q-weighting), the most-visited fallback and the index clamp.  One lane; the root has few edges.
-__device__ inline int best_move_index(const G& s, const Node& r, float qVetoDelta, float qValueWeight) {
-    if (!(r.flags & F_EXPANDED) || r.expanded <= 0) return -1;
-    const Edge* e = edges_of(s, r);
-    const int n = r.expanded;
-    int best = -1;
-    bool decided = false;
-    if (r.type == T_WIN) {
-        int shortest = 0x7fffffff;
-        for (int i = 0; i < r.cntTypes; ++i)
-            if (e[i].ctype == T_LOSS && s.nodes[e[i].child].endInPly < shortest) { shortest = s.nodes[e[i].child].endInPly; best = i; }
-        decided = best >= 0;
-    }
-    if (!decided && r.type == T_LOSS) {
-        best = 0;
-        int longest = 0;
-        for (int i = 0; i < n; ++i) { const int ep = s.nodes[e[i].child].endInPly; if (ep > longest) { longest = ep; best = i; } }
-        decided = true;
-    }
-    if (!decided) {
-        bool hasNonLosing = false;
-        for (int i = 0; i < n; ++i) hasNonLosing |= s.nodes[e[i].child].type != T_WIN;
-        auto eligible = [&](int i) { return !hasNonLosing || s.nodes[e[i].child].type != T_WIN; };
-        int first = 0;
-        while (first < n && !eligible(first)) ++first;
-        if (first == n) best = -1;
-        else {
-            int bestVisitIdx = first, maxVisits = e[first].visits, secondVisitIdx = -1;
-            for (int i = first + 1; i < n; ++i) {
-                if (!eligible(i)) continue;
-                if (e[i].visits > maxVisits) { secondVisitIdx = bestVisitIdx; maxVisits = e[i].visits; bestVisitIdx = i; }
-                else if (secondVisitIdx < 0 || e[i].visits > e[secondVisitIdx].visits) secondVisitIdx = i;
-            }
-            int bestQIdx = first;
-            float bestQ = e[first].q;
-            for (int i = first + 1; i < n; ++i) { if (!eligible(i)) continue; if (e[i].q > bestQ) { bestQ = e[i].q; bestQIdx = i; } }
-            best = bestVisitIdx;
-            bool done = false;
-            if (qVetoDelta > 0.0f && bestQIdx != bestVisitIdx && e[bestQIdx].q > e[bestVisitIdx].q + qVetoDelta && e[bestQIdx].visits > 1) { best = bestQIdx; done = true; }
-            if (!done && qValueWeight > 0.0f && secondVisitIdx >= 0 && e[secondVisitIdx].q > e[bestVisitIdx].q) {
-                const float qDifference = e[secondVisitIdx].q - e[bestVisitIdx].q;
-                const float adjusted = (float)e[secondVisitIdx].visits + qDifference * qValueWeight * (float)e[bestVisitIdx].visits;
-                if (adjusted > (float)e[bestVisitIdx].visits) best = secondVisitIdx;
-            }
-        }
-    }
-    if (best < 0) {                                       // agent.cc:872-880
-        int maxVisits = 0;
-        for (int i = 0; i < n; ++i) if (e[i].visits > maxVisits) { maxVisits = e[i].visits; best = i; }
-    }
-    if (best < 0 || best >= n) best = 0;                  // agent.cc:882-886
-    return best;
 }
 
 // root_edge_stats / root_q (agent.cc:1004-1024): out[g][0] = edge count, then per edge (moveA, moveB, visits).
@@ -1974,6 +2031,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
         inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;
+        inf[16] = gm.reusedVisits; inf[17] = gm.targetNodes; inf[18] = inf[19] = 0;
     }
 }
 
@@ -2035,6 +2093,12 @@ __global__ __launch_bounds__(64) void k_apply(Pools pl, Params prm, const u32* m
 __global__ void k_set_side(Pools pl, int n, const uint8_t* team, const uint8_t* adv) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) { pl.games[g].team = team[g] ? 1 : 0; pl.games[g].adv = adv[g] ? 1 : 0; }
+}
+// tree reuse policy of every game slot (mode[g]: 0 off, 1 reuse when the node budget fits, 2 shrink the budget to fit); reset != 0
+// also forgets the previous search's tree (Agent::reset_search_state, agent.cc:403-412)
+__global__ void k_set_reuse(Pools pl, int n, const uint8_t* mode, int reset) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) { if (mode) pl.games[g].reuseMode = mode[g]; if (reset) pl.games[g].lastRootP1 = 0; }
 }
 // ends the search of the masked games at their next collect (Agent::set_is_running(false), agent.h: the UCI `stop` / movetime path)
 __global__ void k_stop(Pools pl, int n, const uint8_t* mask) {
@@ -2711,6 +2775,22 @@ int hm_sp_set_side(hm_sp* sp, const uint8_t* team, const uint8_t* time_adv) {
     unsigned char* d = reinterpret_cast<unsigned char*>(sp->d_moveA);          // scratch: 8 * G bytes of the input block
     HIPCHK(hipMemcpy(d, hs, 2 * G_, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_side, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, d, d + G_);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+// Tree reuse between the searches of a game slot (Agent::try_reuse_tree / store_next_root_candidates, agent.cc:1345-1451):
+// mode[g] (NULL = leave as is) 0 off (self-play and tournaments: reset_search_state before every search), 1 reuse when the node
+// budget fits behind the nodes already in the pool, 2 also shrink the budget to what fits (time-limited searches); reset != 0
+// forgets the previous trees (Agent::reset_search_state: ucinewgame).
+int hm_sp_set_tree_reuse(hm_sp* sp, const uint8_t* mode, int reset) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    unsigned char* d = reinterpret_cast<unsigned char*>(sp->d_moveA);          // scratch: 8 * G bytes of the input block
+    if (mode) {
+        std::memcpy(sp->h_stage, mode, (size_t)sp->nGames);
+        HIPCHK(hipMemcpy(d, sp->h_stage, (size_t)sp->nGames, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_set_reuse, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, mode ? d : nullptr, reset);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;

@@ -15,7 +15,8 @@
 // The final `info` lines carry MultiPV principal variations (agent.cc:917-965, 1218-1290; walked on the device by hm_sp_pv_lines)
 // and `bestmove` carries the ponder move (agent.cc:1054-1113) when Ponder is on.
 // `go ponder` runs on a worker thread until `ponderhit` (then its budget applies, clock restarted) or `stop`; every other `go` is
-// synchronous.  Not built (documented in DESIGN.md): tree reuse between moves (Agent::try_reuse_tree, agent.cc:1345-1451).  `go movetime` follows the reference's polling loop (early exit on a
+// synchronous.  The search tree is carried from one `go` to the next (Agent::try_reuse_tree / store_next_root_candidates,
+// agent.cc:1345-1451; on the device: k_begin's find_reusable_root) until `ucinewgame` or a setoption that rebuilds the engine.  `go movetime` follows the reference's polling loop (early exit on a
 // solved root / forced mate, early stopping on an insurmountable visit lead, time extension).
 #include <hip/hip_runtime.h>
 
@@ -335,7 +336,17 @@ static void uci_search(hm_uci* u, GoParams gp, std::string& out) {
     const uint64_t seed = 0;
     auto t0 = std::chrono::steady_clock::now();
     auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    // tree reuse (ENABLE_TREE_REUSE, search_params.h:194): a node-limited search keeps its budget, a time-limited one may shrink it
+    // to what the pool still holds behind the retained tree
+    const uint8_t reuseMode = (nodes > 0 && !gp.ponder) ? 1 : 2;
+    if (hm_sp_set_tree_reuse(u->sp, &reuseMode, 0)) { out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
     if (hm_sp_begin_search(u->sp, &target, &seed, 0.0f, 0.0f, &one)) { out += std::string("info string search failed: ") + hm_last_error() + "\nbestmove (none)\n"; return; }
+    {   // "info string Tree reuse: N visits recovered" (agent.cc:519-522)
+        int count = 0;
+        std::vector<int> binfo(HM_SP_INFO_INTS);
+        if (!hm_sp_root_stats(u->sp, &count, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, binfo.data(), hm_sp_max_edges(u->sp)) && binfo[16] >= 0)
+            out += "info string Tree reuse: " + std::to_string(binfo[16]) + " visits recovered\n";
+    }
     int active = 1, which = 0, iters = 0;
     bool stopped = false, wasPondering = gp.ponder;
     void* heads[5] = {u->io.value, u->io.pi_a, u->io.pi_b, u->io.wdl, u->io.moves_left};
@@ -638,7 +649,13 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
     else if (token == "stop") uci_stop(u);
     else if (token == "setoption") { uci_stop(u); uci_setoption(u, is); }
     else if (token == "position") { uci_stop(u); uci_position(u, is); }
-    else if (token == "ucinewgame") { uci_stop(u); hm_board b; hm_board_startpos(&b); (void)uci_set_position(u, b); }   // new_game: search state is per `go` here
+    else if (token == "ucinewgame") {          // UCI::new_game (uci.cc:77-86): reset_search_state drops the retained tree
+        uci_stop(u);
+        hm_board b;
+        hm_board_startpos(&b);
+        (void)uci_set_position(u, b);
+        (void)hm_sp_set_tree_reuse(u->sp, nullptr, 1);
+    }
     else if (token == "policy") { uci_stop(u); uci_policy(u); }
     else if (token == "quit") { uci_stop(u); quit = true; }
     std::lock_guard<std::mutex> lock(u->mu);

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import BOARD_DTYPE, MAX_MOVES, PLANE_VALUES, POLICY_VALUES, HivemindError, check, lib
 
 BATCH = 8   # SearchParams::BATCH_SIZE (search_params.h:26)
-INFO_INTS = 16   # HM_SP_INFO_INTS
+INFO_INTS = 20   # HM_SP_INFO_INTS
 ST_IDLE, ST_SEARCHING, ST_FINISHING, ST_DONE, ST_NOACTION, ST_ERROR = range(6)
 
 
@@ -53,6 +53,7 @@ _SIGS = {
     "hm_sp_profile": (_i, [_vp, _i]),
     "hm_sp_profile_launches": (_i, [_vp, _i]),
     "hm_sp_leg_times": (_i, [_vp, _vp, _vp, _i]),
+    "hm_sp_set_tree_reuse": (_i, [_vp, _vp, _i]),
     "hm_sp_pv_lines": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "hm_sp_leg_clock_net": (_vp, [_vp]),
     "hm_sp_trace_select": (_i, [_i]),

@@ -222,11 +222,19 @@ int hm_sp_active(hm_sp* sp, int* active);
  * joint action Agent::run_search returns (get_best_move_idx_with_q_weight, node.h:656-754 with
  * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13] = leaf move-list words written
  * (traffic accounting), [14] / [15] = solver type (0 unsolved, 1 win, 2 loss, 3 draw — from the child's side) and endInPly of that
- * action's child node (format_uci_score, agent.cc:48-78). */
-#define HM_SP_INFO_INTS 16
+ * action's child node (format_uci_score, agent.cc:48-78), [16] = visits of the root recovered by tree reuse (-1 = fresh root),
+ * [17] = node budget in force (hm_sp_set_tree_reuse), [18..19] reserved. */
+#define HM_SP_INFO_INTS 20
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
                      float* root_q, int* info, int max_edges);
+/* Tree reuse between the searches of a game slot (Agent::try_reuse_tree / store_next_root_candidates, agent.cc:1345-1451): the
+ * next hm_sp_begin_search takes the previous search's selected child, or one of the replies generated below it, as its root when
+ * that node is the new position (hash, side, both boards, history) -- hm_sp_root_stats info[16] = visits recovered, -1 = fresh root.
+ * mode[g] (NULL = unchanged): 0 off (default; self-play and tournaments reset the agent before every search), 1 reuse when the node
+ * budget fits behind the nodes the pool already holds, 2 also shrink the budget to what fits (info[17] = the budget in force).
+ * reset != 0 forgets the previous trees (Agent::reset_search_state, agent.cc:403-412). */
+int hm_sp_set_tree_reuse(hm_sp* sp, const uint8_t* mode, int reset);
 /* Principal variations of one game's search (Agent::extract_pv_from_child, agent.cc:1218-1290): line l starts with root edge
  * child_idx[l] and follows the final-move rule through expanded nodes, max_depth joint actions at most.  The caller orders the
  * root edges (visit count, solver-aware best move first: agent.cc:917-940).  moves[n_lines][max_depth][2]; lens, child_type and
@@ -490,7 +498,8 @@ int hm_move_uci(hm_move move, char* out, int cap);
 /* `info` lines with MultiPV principal variations (agent.cc:917-965,        */
 /* 1218-1290) and `bestmove ... ponder ...` (agent.cc:1054-1113).           */
 /* `go ponder ...` searches on a worker thread until `ponderhit` (then the  */
-/* budget applies) or `stop`.  Not built: tree reuse between moves.         */
+/* budget applies) or `stop`; the tree is reused from one `go` to the next   */
+/* (agent.cc:1345-1451) until `ucinewgame`.                                 */
 /* ================================================================== */
 typedef struct hm_uci hm_uci;
 #define HM_UCI_QUIT (-1000000)

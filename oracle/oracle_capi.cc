@@ -194,6 +194,9 @@ int ora_search_pv_lines(void* sp, int multi_pv, int max_depth, int* out_idx, int
     }
     return (int)lines.size();
 }
+void ora_search_set_tree_reuse(void* sp, int on) { Search* s = static_cast<Search*>(sp); s->enableTreeReuse = on != 0; if (!on) s->reset_search_state(); }
+void ora_search_reset(void* sp) { static_cast<Search*>(sp)->reset_search_state(); }
+int ora_search_reused_visits(void* sp) { return static_cast<Search*>(sp)->reusedVisits; }
 void ora_search_info(void* sp, int* out /*8*/) {
     Search* s = static_cast<Search*>(sp);
     out[0] = s->nodesSearched; out[1] = s->evalRows; out[2] = s->evalCalls; out[3] = s->sameBatchCollisions;

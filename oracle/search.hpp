@@ -956,7 +956,51 @@ public:
 
     // Agent::run_search node-budget path (agent.cc:421-558, 331-352, 808-839). Returns false when the
     // position is terminal / has no action ("bestmove (none)").
+    // Tree reuse between searches (Agent::try_reuse_tree / store_next_root_candidates, agent.cc:1345-1451; ENABLE_TREE_REUSE,
+    // search_params.h:194).  Off by default: self-play and tournaments call Agent::reset_search_state before every search
+    // (selfplay.cc:653, tournament.cc:383); the UCI front end keeps the candidates from one `go` to the next.
+    struct Retained { std::shared_ptr<Node> node; uint64_t positionHash; std::string signature; };
+    std::vector<Retained> nextRootCandidates;
+    bool enableTreeReuse = false;
+    int reusedVisits = -1;                       // visits of the recovered root ("info string Tree reuse: N visits recovered"), -1 = fresh root
+    static std::string board_signature(Board& b) { return b.pos[0].fen() + "|" + b.pos[1].fen(); }
+    void reset_search_state() { root.reset(); nextRootCandidates.clear(); tt.clear(); }   // agent.cc:403-412
+    std::shared_ptr<Node> try_reuse_tree(uint64_t positionHash, int team, const std::string& signature) {
+        std::shared_ptr<Node> reused;
+        for (const Retained& c : nextRootCandidates)
+            if (c.node && c.positionHash == positionHash && c.node->team == team && !c.signature.empty() && c.signature == signature) { reused = c.node; break; }
+        nextRootCandidates.clear();
+        return reused;
+    }
+    void store_next_root_candidates(Board& board, bool adv) {
+        nextRootCandidates.clear();
+        if (!root || !root->isExpanded) return;
+        if (root->children.empty() || root->childVisits.empty()) return;
+        int bestIdx = root->get_best_move_idx_with_q_weight(cfg.qVetoDelta, cfg.qValueWeight);
+        if (bestIdx < 0) {
+            int maxVisits = 0;
+            for (size_t i = 0; i < root->childVisits.size(); ++i) if (root->childVisits[i] > maxVisits) { maxVisits = root->childVisits[i]; bestIdx = (int)i; }
+        }
+        if (bestIdx < 0 || (size_t)bestIdx >= root->children.size()) return;
+        const Candidate own = root->gen.generated[bestIdx];
+        Board ownNext(board);
+        ownNext.make_moves(own.moveA, own.moveB);
+        const std::shared_ptr<Node>& ownNextRoot = root->children[bestIdx];
+        nextRootCandidates.push_back({ownNextRoot, ownNext.hash_key(!adv), board_signature(ownNext)});
+        if (!ownNextRoot || !ownNextRoot->isExpanded || ownNextRoot->children.empty()) return;
+        Board reply(ownNext);
+        for (size_t i = 0; i < ownNextRoot->children.size(); ++i) {
+            if (!ownNextRoot->children[i]) continue;
+            const Candidate r = ownNextRoot->gen.generated[i];
+            reply.make_moves(r.moveA, r.moveB);
+            nextRootCandidates.push_back({ownNextRoot->children[i], reply.hash_key(adv), board_signature(reply)});
+            reply.unmake_moves(r.moveA, r.moveB);
+        }
+    }
+
     bool run(Board& board, int team, bool adv, int targetNodes) {
+        if (!enableTreeReuse) nextRootCandidates.clear();
+        reusedVisits = -1;
         root.reset(); tt.clear();
         nodesSearched = 0; pendingBatchIndex = -1; rootTeam = team;
         const bool aOn = board.pos[0].stm == team, bOn = board.pos[1].stm == (team ^ 1);
@@ -987,10 +1031,20 @@ public:
             }
             root->update(0, 1.0f);
             root->mark_as_win(1);
+            if (enableTreeReuse) store_next_root_candidates(board, adv);
             return true;
         }
-        root = std::make_shared<Node>(team, board.hash_key(adv));
-        root->id = nodeCounter++;
+        const uint64_t positionHash = board.hash_key(adv);
+        std::shared_ptr<Node> reused = enableTreeReuse ? try_reuse_tree(positionHash, team, board_signature(board)) : nullptr;
+        if (reused) {                                   // agent.cc:514-525
+            root = reused;
+            root->hash = positionHash;
+            root->depth = 0;
+            reusedVisits = root->visits;
+        } else {
+            root = std::make_shared<Node>(team, positionHash);
+            root->id = nodeCounter++;
+        }
         if (cfg.enableTranspositions) tt.emplace(root->hash, root);
         while (nodesSearched < targetNodes) {
             if (root->nodeType != NodeType::UNSOLVED) break;
@@ -998,6 +1052,7 @@ public:
         }
         if (root->nodeType != NodeType::UNSOLVED) discard_pending_iteration();
         else finish_pending_iteration(board, adv);
+        if (enableTreeReuse) store_next_root_candidates(board, adv);
         return true;
     }
 

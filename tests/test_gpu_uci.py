@@ -209,6 +209,81 @@ def test_policy_command_matches_oracle(hm):
         u.close()
 
 
+def _tokens(joint):
+    """'(e2e4,pass)' -> ['1e2e4']: the `position ... moves` tokens of a joint action"""
+    a, b = joint.strip("()").split(",")
+    return [f"{bd + 1}{m}" for bd, m in ((0, a), (1, b)) if m != "pass"]
+
+
+@pytest.mark.parametrize("switch_side,nodes,max_nodes", [(False, 400, 4000), (True, 400, 4000), (False, 100, 560), (True, 120, 560)])
+def test_tree_reuse_between_searches_matches_oracle(hm, switch_side, nodes, max_nodes):
+    """ENABLE_TREE_REUSE (search_params.h:194; Agent::try_reuse_tree / store_next_root_candidates, agent.cc:1345-1451): the next `go`
+    starts from the retained subtree when the new position is the selected child (engine switched to the other team) or one of the
+    replies generated below it (same team, after the predicted reply); `ucinewgame` drops it.  Every search ≡ the CPU restatement
+    running the same sequence with tree reuse on: recovered visits, node count, best move, the whole PV."""
+    # max_nodes 560: the node pool is small enough for k_collect's LDS mirror (hm_search.hip), now with a root that is not node 0
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=max_nodes)
+    s = O.Search(1, 1)
+    s.set_tree_reuse(True)
+    moves = ["1e2e4", "2d2d4"]
+    team, adv = 0, False
+    recovered = []
+    for step in range(4):
+        u.command(f"setoption name Team value {'white' if team == 0 else 'black'}")
+        u.command(f"setoption name Mode value {'sit' if adv else 'go'}")
+        u.command("position startpos moves " + " ".join(moves))
+        text, _ = u.command(f"go nodes {nodes}")
+        lines = text.strip().split("\n")
+        assert s.run(_oracle_board(None, moves), team, adv, nodes)
+        rv = s.reused_visits()
+        recovered.append(rv)
+        reuse_lines = [l for l in lines if l.startswith("info string Tree reuse")]
+        assert reuse_lines == ([f"info string Tree reuse: {rv} visits recovered"] if rv >= 0 else []), (step, lines, rv)
+        pv = s.pv_lines(1, 20)[0]
+        info = [l for l in lines if l.startswith("info depth")][0]
+        m = re.match(r"info depth \d+ score (cp|mate) -?\d+ nodes (\d+) nps \d+ hashfull 0 tbhits 0 time \d+ pv (\(.*\))$", info)
+        assert m and int(m.group(2)) == s.info()["nodes"], (step, info, s.info())
+        assert m.group(3) == " ".join(_joint(a, b) for a, b in pv["moves"]), (step, info, pv)
+        assert lines[-1].startswith("bestmove " + _joint(*pv["moves"][0])), (step, lines[-1])
+        assert len(pv["moves"]) >= 2
+        moves += _tokens(_joint(*pv["moves"][0]))
+        if switch_side:                       # the engine now answers for the other team: the selected child is the new root
+            team, adv = team ^ 1, not adv
+        else:                                 # the predicted reply is played: one of the retained replies is the new root
+            moves += _tokens(_joint(*pv["moves"][1]))
+    assert recovered[0] == -1 and all(r > 0 for r in recovered[1:]), recovered
+    # ucinewgame: reset_search_state (uci.cc:77-86) -- the same position is searched from a fresh root again
+    u.command("ucinewgame")
+    s.reset()
+    u.command(f"setoption name Team value {'white' if team == 0 else 'black'}")
+    u.command(f"setoption name Mode value {'sit' if adv else 'go'}")
+    u.command("position startpos moves " + " ".join(moves))
+    text, _ = u.command(f"go nodes {nodes}")
+    assert "Tree reuse" not in text
+    assert s.run(_oracle_board(None, moves), team, adv, nodes) and s.reused_visits() == -1
+    pv = s.pv_lines(1, 20)[0]
+    assert text.strip().split("\n")[-1].startswith("bestmove " + _joint(*pv["moves"][0]))
+    u.close()
+
+
+def test_tree_reuse_falls_back_when_the_pool_is_full(hm):
+    """the retained tree stays in the node pool; when the next node budget no longer fits behind it the search starts from an
+    empty pool (a bounded-memory deviation from the reference, which keeps reusing) and still answers"""
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=300)
+    moves = ["1e2e4", "2d2d4"]
+    seen = []
+    for step in range(4):
+        u.command("position startpos moves " + " ".join(moves))
+        text, _ = u.command("go nodes 300")
+        lines = text.strip().split("\n")
+        seen.append(any(l.startswith("info string Tree reuse") for l in lines))
+        best = re.match(r"bestmove (\(\S+\)) ponder (\(\S+\))", lines[-1])
+        assert best, lines
+        moves += _tokens(best.group(1)) + _tokens(best.group(2))
+    assert seen == [False] * 4, seen                       # 300 more nodes never fit behind a 300-node tree in a 300-node pool
+    u.close()
+
+
 def _wait_for_bestmove(u, limit_s=20.0):
     import time
     text, t0 = "", time.time()
