@@ -353,6 +353,7 @@ static void uci_search(hm_uci* u, GoParams gp, std::string& out) {
     hm_time_manager tm;
     tm.moveTimeMs = moveTime; tm.effectiveMs = moveTime;
     double lastPoll = 0.0;
+    int lastReportedDepth = 0;
     const int E0 = hm_sp_max_edges(u->sp);
     std::vector<int> pv(E0), pinfo(HM_SP_INFO_INTS), ptype(E0), pend(E0);
     std::vector<float> pq(E0);
@@ -399,6 +400,19 @@ static void uci_search(hm_uci* u, GoParams gp, std::string& out) {
                     if (pinfo[12] >= 0 && pinfo[12] < count) { ptype[pinfo[12]] = pinfo[14]; pend[pinfo[12]] = pinfo[15]; }
                     stop = tm_poll(tm, now, pinfo[1], count, pv.data(), pq.data(), pinfo[6] > 0 ? pinfo[6] : 0, ptype.data(), pend.data());
                     out += tm.log; tm.log.clear();
+                    // "Report each completed depth once" (agent.cc:680-711): the solver-aware best line so far
+                    if (!stop && pinfo[9] > lastReportedDepth && count > 0 && pinfo[12] >= 0 && pinfo[12] < count) {
+                        lastReportedDepth = pinfo[9];
+                        const int ci = pinfo[12];
+                        int len = 0, ct = 0, ce = 0;
+                        hm_move line[40];
+                        if (!hm_sp_pv_lines(u->sp, 0, 1, &ci, 20, line, &len, &ct, &ce)) {
+                            std::string s = "info depth " + std::to_string(pinfo[9]) + " " + uci_score(ct, ce, pq[ci]) + " nodes " + std::to_string(pinfo[1]) + " nps "
+                                            + std::to_string(now > 0 ? (int)(pinfo[1] * 1000.0 / now) : 0) + " hashfull 0 tbhits 0 time " + std::to_string((int)now);
+                            for (int d = 0; d < len; ++d) s += std::string(d == 0 ? " pv " : " ") + "(" + uci_text(line[2 * d]) + "," + uci_text(line[2 * d + 1]) + ")";
+                            out += s + "\n";
+                        }
+                    }
                 }
             }
             if (stop) { (void)hm_sp_stop(u->sp, nullptr, nullptr); stopped = true; }

@@ -326,7 +326,7 @@ def test_go_ponder_runs_until_ponderhit_or_stop(hm):
     u.command("ponderhit")
     text = _wait_for_bestmove(u)
     dt = (time.time() - t0) * 1e3
-    info = [l for l in text.split("\n") if l.startswith("info depth")][0]
+    info = [l for l in text.split("\n") if l.startswith("info depth")][-1]
     assert 100 <= int(re.search(r" time (\d+) ", info).group(1)) < 1500 and dt >= 100, (info, dt)
     # a new command while pondering stops the search first (UCI::go / setoption call stop(), uci.cc:160, 217)
     u.command("go ponder nodes 100")
@@ -361,7 +361,11 @@ def test_go_movetime_returns_a_legal_best_move(hm):
     b = _oracle_board(None, ["1e2e4", "2e2e4"])
     for bd, mv in ((0, m.group(1)), (1, m.group(2))):
         assert mv == "pass" or b.find_move(bd, mv) != 0, (bd, mv)
-    info = [l for l in text.split("\n") if l.startswith("info depth")][0]
-    t = int(re.search(r" time (\d+) ", info).group(1))
-    assert 55 <= t < 1500, info                                              # ran to the deadline, then finished the batches in flight
+    infos = [l for l in text.split("\n") if l.startswith("info depth")]
+    t = int(re.search(r" time (\d+) ", infos[-1]).group(1))
+    assert 55 <= t < 1500, infos[-1]                                         # ran to the deadline, then finished the batches in flight
+    # "Report each completed depth once" (agent.cc:680-711): one line per new maximum depth while the clock runs, then the final line
+    depths = [int(l.split()[2]) for l in infos]
+    assert len(infos) >= 3 and depths[:-1] == sorted(set(depths[:-1])) and depths[-1] == depths[-2], depths
+    assert all(" pv (" in l for l in infos)
     u.close()
