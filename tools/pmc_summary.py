@@ -22,12 +22,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CORRECTION = {"FETCH_SIZE": 2, "WRITE_SIZE": 1}
+HOST_ONLY = {"hm_uci.hip"}          # host C++ without device code (the UCI front end): editing it cannot change a kernel
 
 
 def source_hash(root=ROOT):
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(root, "hivemind_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "hivemind_amd", "csrc", "*.hpp"))
                    + [os.path.join(root, "include", "hivemind_amd.h")])
+    files = [f for f in files if os.path.basename(f) not in HOST_ONLY]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
