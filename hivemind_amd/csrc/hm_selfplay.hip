@@ -337,12 +337,11 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     // host does not poll (and so does not synchronise) before that many iterations have been enqueued.
     const int noPollBefore = minTarget / 8 - 1;
     // Leg timings.  Native evaluator: the device-side leg clock (hm_sp_leg_times) -- every launch, graph-replayed ones included,
-    // stamps its own start and end, so the totals are exact and cost the host nothing.  Callback evaluator: HIP events on the null
-    // stream around each leg.
+    // stamps its own start and end, so the totals are exact and cost the host nothing; it is reset and read once per run
+    // (leg_clock_begin / leg_clock_end).  Callback evaluator: HIP events on the null stream around each leg.
     int harvested = 0, nSamples = 0;
     double sum[3] = {0.0, 0.0, 0.0};
     auto is_timed = [&](int) { return !native; };
-    if (native) if (int rc = hm_sp_leg_times(s->sp, nullptr, nullptr, 1)) return rc;
     auto harvest = [&](int upto) {                 // leg timings of the sampled iterations in [harvested, upto)
         for (int it = harvested; it < upto; ++it) {
             if (!is_timed(it)) continue;
@@ -357,9 +356,9 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
     };
     if (native && s->graphState == 0) build_step_graph(s, allRows);
     while (active > 0) {
-        // The first GRAPH_ITERS iterations of every search are enqueued eagerly; after that the loop replays the captured graph,
-        // GRAPH_ITERS iterations per launch, polling the active-game count once per launch.
-        if (native && s->graphState == 1 && iters >= GRAPH_ITERS && which == 0) {
+        // Once captured (during the first search), the graph is replayed from the first iteration of every search, GRAPH_ITERS
+        // iterations per launch, polling the active-game count once per launch.
+        if (native && s->graphState == 1 && which == 0) {
             if (hipGraphLaunch(s->stepGraph, s->sT) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipGraphLaunch failed");
             iters += GRAPH_ITERS;
             s->res.eval_batches += GRAPH_ITERS;
@@ -419,11 +418,7 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         if (poll && !(native && s->graphState == 1)) harvest(iters);
         if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
     }
-    if (native) {                                  // the tree stream was synchronised by the last poll
-        double ms[3];
-        if (int rc = hm_sp_leg_times(s->sp, ms, nullptr, 0)) return rc;
-        s->res.collect_ms += ms[0]; s->res.eval_ms += ms[1]; s->res.process_ms += ms[2];
-    } else harvest(iters);
+    if (!native) harvest(iters);                   // native: the leg clock is read once per run (leg_clock_end)
     if (nSamples > 0) {
         const double w = (double)iters / nSamples;
         s->res.collect_ms += w * sum[0]; s->res.eval_ms += w * sum[1]; s->res.process_ms += w * sum[2];
@@ -515,13 +510,25 @@ int hm_selfplay_set_output_directory(hm_selfplay* s, const char* dir) {
     return 0;
 }
 
+// leg clock of a run with the native evaluator: cleared at the start, totals added to the result at the end (all streams idle)
+static void leg_clock_begin(hm_selfplay* s) { if (s->io.net) (void)hm_sp_leg_times(s->sp, nullptr, nullptr, 1); }
+static void leg_clock_end(hm_selfplay* s) {
+    if (!s->io.net) return;
+    (void)hipDeviceSynchronize();
+    double ms[3] = {0.0, 0.0, 0.0};
+    if (hm_sp_leg_times(s->sp, ms, nullptr, 1)) return;
+    s->res.collect_ms += ms[0]; s->res.eval_ms += ms[1]; s->res.process_ms += ms[2];
+}
+
 // run_selfplay (selfplay.cc:558-748).  Whatever the outcome, the samples of every finished game are handed to the chunk
 // sink before returning (ChunkWriter::finish :87-91), so an error late in a run does not discard the games before it.
 int hm_selfplay_run(hm_selfplay* s, hm_selfplay_result* out) {
     if (!s) return hm_fail(HM_ERR_INVALID, "null argument");
     const auto t0 = std::chrono::steady_clock::now();
+    leg_clock_begin(s);
     const int rc = selfplay_run_impl(s);
     const std::string msg = rc ? std::string(hm_last_error()) : std::string();
+    leg_clock_end(s);
     if (has_sink(s) && !s->sampleEnd.empty()) flush_chunk(s, s->sampleEnd.size());
     s->res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     s->res.record_bytes = s->records.size();
@@ -1108,8 +1115,10 @@ int hm_tournament_run(hm_tournament* t, hm_tournament_result* out) {
     const auto t0 = std::chrono::steady_clock::now();
     t->res = hm_tournament_result{};
     t->core->res = hm_selfplay_result{};
+    leg_clock_begin(t->core);
     const int rc = tournament_run_impl(t);
     const std::string msg = rc ? std::string(hm_last_error()) : std::string();
+    leg_clock_end(t->core);
     tournament_account(t);
     t->res.search_iterations = t->core->res.search_iterations;
     t->res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
