@@ -136,6 +136,10 @@ struct hm_selfplay {
     hipEvent_t gFork = nullptr, gJoin = nullptr;
     hipEvent_t gCollected[2] = {nullptr, nullptr};
     int graphState = 0;                            // 0 not tried, 1 ready, -1 unavailable (eager loop)
+    // time-managed searches (tournaments with a movetime limit): every searching slot has its own controller of the reference's
+    // polling loop (agent.cc:715-806: deadline, early stopping, time extension); 0 = node-limited searches
+    int moveTimeMs = 0;
+    std::vector<hm_time_manager*> timeCtl;
     int32_t* d_rows[2] = {nullptr, nullptr};   // per game slot: plane rows written into planes[k] (ragged evaluator batch)
     // second network (tournaments: contender = io.net, baseline = net2): every slot's search is evaluated by the network of
     // the team to move, so each iteration launches both forwards over disjoint row sets
@@ -355,6 +359,44 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         harvested = upto;
     };
     if (native && s->graphState == 0) build_step_graph(s, allRows);
+    // Time-managed search: every 5 ms (agent.cc:562) the root statistics of all slots go through their controllers; slots told to
+    // stop end at their next collect (finishing the batch in flight), the search ends when no slot is left.
+    const bool timed = native && s->moveTimeMs > 0;
+    const auto tStart = std::chrono::steady_clock::now();
+    double lastCtl = 0.0;
+    std::vector<int> tcCounts, tcVisits, tcInfo, tcType, tcEnd;
+    std::vector<float> tcQ;
+    std::vector<uint8_t> tcStop, tcStopped;
+    if (timed) {
+        const int E = hm_sp_max_edges(s->sp);
+        tcCounts.resize(s->G); tcVisits.resize((size_t)s->G * E); tcQ.resize((size_t)s->G * E); tcInfo.resize((size_t)s->G * HM_SP_INFO_INTS);
+        tcType.resize(E); tcEnd.resize(E); tcStop.assign(s->G, 0); tcStopped.assign(s->G, 0);
+        for (auto*& m : s->timeCtl) { if (m) hm_time_manager_destroy(m); m = nullptr; }
+        s->timeCtl.assign(s->G, nullptr);
+        for (int g = 0; g < s->G; ++g) s->timeCtl[g] = hm_time_manager_create(s->moveTimeMs);
+    }
+    auto time_control = [&]() -> int {             // the tree stream is idle (called right after a poll)
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count();
+        if (now - lastCtl < 5.0) return 0;
+        lastCtl = now;
+        const int E = hm_sp_max_edges(s->sp);
+        if (int rc = hm_sp_root_stats(s->sp, tcCounts.data(), nullptr, nullptr, tcVisits.data(), tcQ.data(), nullptr, nullptr, tcInfo.data(), E)) return rc;
+        bool anyStop = false;
+        std::fill(tcStop.begin(), tcStop.end(), 0);
+        for (int g = 0; g < s->G; ++g) {
+            const int* inf = tcInfo.data() + (size_t)g * HM_SP_INFO_INTS;
+            if (inf[0] != 1 || tcStopped[g]) continue;                        // not searching (ST_SEARCHING = 1) or already told to stop
+            const int n = tcCounts[g];
+            std::fill(tcType.begin(), tcType.begin() + n, 0); std::fill(tcEnd.begin(), tcEnd.begin() + n, 0);
+            if (inf[12] >= 0 && inf[12] < n) { tcType[inf[12]] = inf[14]; tcEnd[inf[12]] = inf[15]; }
+            const int stop = hm_time_manager_poll(s->timeCtl[g], now, inf[1], n, tcVisits.data() + (size_t)g * E, tcQ.data() + (size_t)g * E, inf[6] > 0 ? inf[6] : 0,
+                                                  tcType.data(), tcEnd.data(), nullptr, nullptr, 0);
+            if (stop < 0) return stop;
+            if (stop) { tcStop[g] = 1; tcStopped[g] = 1; anyStop = true; }
+        }
+        if (anyStop) return hm_sp_stop(s->sp, tcStop.data(), s->sT);
+        return 0;
+    };
     while (active > 0) {
         // Once captured (during the first search), the graph is replayed from the first iteration of every search, GRAPH_ITERS
         // iterations per launch, polling the active-game count once per launch.
@@ -362,9 +404,10 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             if (hipGraphLaunch(s->stepGraph, s->sT) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipGraphLaunch failed");
             iters += GRAPH_ITERS;
             s->res.eval_batches += GRAPH_ITERS;
-            if (iters >= noPollBefore) {
+            if (iters >= noPollBefore || timed) {
                 if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;
                 active = *s->hActive;
+                if (timed && active > 0) if (int rc = time_control()) return rc;
             }
             if (iters > 100000) return hm_fail(HM_ERR_STATE, "search did not terminate");
             continue;
@@ -396,9 +439,10 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             if (int rc = hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT)) return rc;
             if (timed) (void)hipEventRecord(e[5], s->sT);
             (void)hipEventRecord(y[1], s->sT);
-            if (poll) {
+            if (poll || timed) {
                 if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;     // async copy + stream sync
                 active = *s->hActive;
+                if (timed && active > 0) if (int rc = time_control()) return rc;
             }
         } else {
             (void)hipEventRecord(e[0], nullptr);
@@ -486,6 +530,7 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     for (hipEvent_t e : s->gCollected) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->evs) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->sync) if (e) (void)hipEventDestroy(e);
+    for (hm_time_manager* m : s->timeCtl) if (m) hm_time_manager_destroy(m);
     delete s;
     return 0;
 }
@@ -877,6 +922,7 @@ struct hm_tournament {
     std::vector<uint8_t> acting;    // per slot: 1 = the contender's network evaluates the search in flight
     std::vector<double> pairScores;
     size_t nextGame = 0;
+    int poolNodes = 0;              // node target handed to every search: the node budget, or the pool size of a time-limited search
     hm_tournament_result res{};
 };
 
@@ -945,13 +991,13 @@ static int tournament_run_impl(hm_tournament* t) {
             const bool contenderActing = sl.active && sl.team == sl.contenderTeam;
             t->acting[g] = contenderActing ? 1 : 0;
             profile[g] = contenderActing ? 0 : 1;                              // schedule 0 = contender's PW coefficient, 1 = baseline's
-            target[g] = (int)c.nodes;
+            target[g] = t->poolNodes;                                          // the node budget, or the pool size of a time-limited search
             seeds[g] = sl.active ? tournament_seed(c.seed, (sl.gameIndex / 2) * c.max_macro_plies + sl.macroPly) : 0;
         }
         if (int rc = hm_sp_set_pw_profiles(s->sp, c.baseline_pw_coefficient, c.baseline_pw_coefficient, profile.data())) return rc;
         if (s->d_netSel && hipMemcpy(s->d_netSel, profile.data(), (size_t)G, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
         if (int rc = hm_sp_begin_search(s->sp, target.data(), seeds.data(), c.dirichlet_alpha, c.dirichlet_epsilon, mask.data())) return rc;
-        if (int rc = run_search_lockstep(s, (int)c.nodes)) return rc;
+        if (int rc = run_search_lockstep(s, c.move_time_ms > 0 ? 0 : (int)c.nodes)) return rc;
         if (int rc = hm_sp_root_stats(s->sp, counts.data(), mA.data(), mB.data(), visits.data(), nullptr, nullptr, rootQ.data(), info.data(), E)) return rc;
         std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0); std::fill(applyMask.begin(), applyMask.end(), 0);
         for (int g = 0; g < G; ++g) {
@@ -1065,6 +1111,7 @@ extern "C" {
 void hm_tournament_config_default(hm_tournament_config* c) {   // tools/tournament.h:15-27
     if (!c) return;
     std::memset(c, 0, sizeof *c);
+    c->max_search_nodes = 0;
     c->games = 20; c->nodes = 400; c->move_time_ms = 0; c->contender_batch_size = 8; c->baseline_batch_size = 8;
     c->max_macro_plies = 400; c->dirichlet_alpha = 0.3f; c->dirichlet_epsilon = 0.10f;
     c->contender_pw_coefficient = 2.0f; c->baseline_pw_coefficient = 2.0f; c->seed = 1; c->concurrent_games = 64;
@@ -1082,13 +1129,16 @@ int hm_tournament_create(const hm_tournament_config* cfg, const hm_search_config
     if (!std::isfinite(c.contender_pw_coefficient) || !std::isfinite(c.baseline_pw_coefficient) || c.contender_pw_coefficient <= 0.0f || c.baseline_pw_coefficient <= 0.0f)
         return hm_fail(HM_ERR_INVALID, "Tournament PW coefficients must be positive and finite");
     // what this engine does not build
-    if (c.move_time_ms > 0) return hm_fail(HM_ERR_INVALID, "time-managed tournament search is not built: give a node budget");
+    if (c.move_time_ms > 0 && !io->net) return hm_fail(HM_ERR_INVALID, "a movetime tournament is built for the native evaluator only (two networks)");
+    if (c.move_time_ms > 0 && c.max_search_nodes < 0) return hm_fail(HM_ERR_INVALID, "max_search_nodes must not be negative");
     if (c.contender_batch_size != 8 || c.baseline_batch_size != 8) return hm_fail(HM_ERR_INVALID, "only the default batch size 8 is built");
     if (c.concurrent_games < 1) return hm_fail(HM_ERR_INVALID, "concurrent_games must be positive");
     if ((io->net != nullptr) != (baseline_net != nullptr)) return hm_fail(HM_ERR_INVALID, "give both networks, or a callback that serves both");
     hm_selfplay_config sc;
     hm_selfplay_config_default(&sc);
-    sc.games = c.games; sc.nodes = c.nodes; sc.max_macro_plies = c.max_macro_plies; sc.node_random_factor = 0.0;
+    // a time-limited search has no node budget: its pool holds max_search_nodes (default 4096) and the search ends there at the latest
+    const uint64_t poolNodes = c.move_time_ms > 0 ? (uint64_t)(c.max_search_nodes > 0 ? c.max_search_nodes : 4096) : c.nodes;
+    sc.games = c.games; sc.nodes = poolNodes; sc.max_macro_plies = c.max_macro_plies; sc.node_random_factor = 0.0;
     sc.seed = c.seed ? c.seed : 1; sc.concurrent_games = (int)std::min<uint64_t>((uint64_t)c.concurrent_games, c.games);
     hm_search_config search;
     if (scfg) search = *scfg; else hm_search_config_default(&search);
@@ -1099,6 +1149,8 @@ int hm_tournament_create(const hm_tournament_config* cfg, const hm_search_config
     t->cfg.concurrent_games = sc.concurrent_games;
     if (int rc = hm_selfplay_create(&sc, &search, io, fn, user, &t->core)) { delete t; return rc; }
     hm_selfplay* s = t->core;
+    s->moveTimeMs = c.move_time_ms > 0 ? c.move_time_ms : 0;
+    t->poolNodes = (int)poolNodes;
     if (baseline_net) {
         s->net2 = baseline_net;
         bool ok = hipMalloc(&s->d_netSel, (size_t)s->G) == hipSuccess;

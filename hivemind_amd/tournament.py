@@ -17,7 +17,7 @@ class TournamentConfig(C.Structure):
     _fields_ = [("games", C.c_uint64), ("nodes", C.c_uint64), ("move_time_ms", C.c_int32), ("contender_batch_size", C.c_int32),
                 ("baseline_batch_size", C.c_int32), ("max_macro_plies", C.c_uint64), ("dirichlet_alpha", C.c_float),
                 ("dirichlet_epsilon", C.c_float), ("contender_pw_coefficient", C.c_float), ("baseline_pw_coefficient", C.c_float),
-                ("seed", C.c_uint64), ("concurrent_games", C.c_int32)]
+                ("seed", C.c_uint64), ("concurrent_games", C.c_int32), ("max_search_nodes", C.c_int32)]
 
 
 class TournamentBreakdown(C.Structure):

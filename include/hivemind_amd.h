@@ -437,8 +437,11 @@ int hm_hvm4_write_chunk(const char* path, const uint8_t* records, uint64_t nbyte
 /* (no shared RNG), so they run in lockstep slots; results, summary.json   */
 /* and games.pgn are produced in game order and are byte-identical to the  */
 /* sequential loop under the same evaluators.                              */
-/* Not built: move_time_ms > 0 (time-managed search) and batch sizes other */
-/* than 8 -> HM_ERR_INVALID at create.                                     */
+/* move_time_ms > 0 (instead of nodes): every search runs until its slot's */
+/* controller of the reference's polling loop says stop (deadline, early   */
+/* stopping, time extension: agent.cc:715-806) -- wall-clock dependent, so */
+/* not reproducible run to run; native evaluator only.  Not built: batch   */
+/* sizes other than 8 -> HM_ERR_INVALID at create.                         */
 /* ================================================================== */
 typedef struct hm_tournament hm_tournament;
 typedef struct hm_tournament_config {     /* TournamentConfig, tools/tournament.h:15-42 */
@@ -449,6 +452,7 @@ typedef struct hm_tournament_config {     /* TournamentConfig, tools/tournament.
     float    contender_pw_coefficient, baseline_pw_coefficient;
     uint64_t seed;
     int32_t  concurrent_games;            /* game slots searched in lockstep on this GPU */
+    int32_t  max_search_nodes;            /* move_time_ms > 0: nodes the pool of one time-limited search holds (0 = 4096); the search ends there at the latest */
 } hm_tournament_config;
 void hm_tournament_config_default(hm_tournament_config* cfg);
 typedef struct hm_tournament_breakdown { uint64_t wins, losses, draws; } hm_tournament_breakdown;

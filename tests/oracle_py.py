@@ -334,14 +334,14 @@ class TournamentCfg(C.Structure):
     _fields_ = [("games", C.c_uint64), ("nodes", C.c_uint64), ("move_time_ms", C.c_int32), ("contender_batch_size", C.c_int32),
                 ("baseline_batch_size", C.c_int32), ("max_macro_plies", C.c_uint64), ("dirichlet_alpha", C.c_float),
                 ("dirichlet_epsilon", C.c_float), ("contender_pw_coefficient", C.c_float), ("baseline_pw_coefficient", C.c_float),
-                ("seed", C.c_uint64), ("concurrent_games", C.c_int32)]
+                ("seed", C.c_uint64), ("concurrent_games", C.c_int32), ("max_search_nodes", C.c_int32)]
 
 
 def tournament_cfg(**kw):
     """Reference defaults (tools/tournament.h:15-27) with overrides."""
     c = TournamentCfg(games=20, nodes=400, move_time_ms=0, contender_batch_size=8, baseline_batch_size=8, max_macro_plies=400,
                       dirichlet_alpha=0.3, dirichlet_epsilon=0.10, contender_pw_coefficient=2.0, baseline_pw_coefficient=2.0,
-                      seed=1, concurrent_games=64)
+                      seed=1, concurrent_games=64, max_search_nodes=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

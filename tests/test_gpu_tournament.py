@@ -73,3 +73,36 @@ def test_tournament_native_networks_and_report_files(hm, tmp_path):
     t.run()
     assert t.pgn("a", "b") != texts[0][0]
     t.close()
+
+
+def test_tournament_with_a_movetime_limit(hm):
+    """TournamentConfig::moveTimeMs instead of nodes (tournament.h:17-18): every search runs under its slot's controller of the
+    reference's polling loop (agent.cc:715-806).  Wall-clock dependent, so the checks are behavioural: searches last about the move
+    time (early stopping may cut them short, two extensions of 1.5x may lengthen them), every game ends, the reports are well formed,
+    far more nodes per move than a handful, and no search outgrows its pool."""
+    import time
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    a = N.FusedNet(N.rise_v3_small())
+    torch.manual_seed(1)
+    b = N.FusedNet(N.rise_v3_small())
+    move_ms, plies = 30, 8
+    cfg = hm.default_tournament_config(games=4, nodes=0, move_time_ms=move_ms, max_macro_plies=plies, seed=9, concurrent_games=4, max_search_nodes=3000)
+    t = hm.Tournament(cfg, contender=a, baseline=b)
+    t0 = time.time()
+    res = t.run()
+    dt = time.time() - t0
+    assert res.games == 4 and res.macro_ply_limits + res.checkmates + res.drawn_terminations + res.no_legal_actions == 4
+    searches = res.searched_positions
+    assert 4 <= searches <= 4 * plies
+    # all four games search in lockstep: at most `plies` rounds, each between a fraction of the move time and 2.25x + slack
+    assert dt < plies * (move_ms * 2.25 + 40) * 1e-3 + 2.0, dt
+    assert res.total_nodes / searches > 20, (res.total_nodes, searches)
+    assert res.total_nodes / searches <= 3000 * 1.05 + 16
+    s = json.loads(t.summary("a", "b"))
+    assert s["move_time_ms"] == move_ms and s["nodes_per_move"] == 0 and s["games"] == 4
+    assert t.pgn("a", "b").count("[Event ") == 4
+    t.close()
+    # a node budget and a move time together are refused (tournament.cc:338-341)
+    with pytest.raises(hm.HivemindError, match="exactly one positive nodes or movetime"):
+        hm.Tournament(hm.default_tournament_config(games=2, nodes=100, move_time_ms=10), contender=a, baseline=b)
