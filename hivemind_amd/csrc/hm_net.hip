@@ -29,6 +29,7 @@ int hm_fail(int code, const std::string& msg);
 namespace hmn {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h16;
 
@@ -665,29 +666,45 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 __syncthreads();
                 for (int c = tid; c < C; c += 512) Mv[c] = (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]) * (1.0f / 64.0f);
                 __syncthreads();
-                for (int it = tid; it < 4 * C; it += 512) {
-                    const int c = it % C, p = it / C;
+                // W_eca (dense [ci][co], 2*C*C bytes from L2) . mean: work item = (1/32 of the input channels, 8 adjacent output
+                // channels) -- 16-byte loads, 32*C/8 items = three per thread at C = 384, a thread's 12 rows requested together; the
+                // 32 partial sums per channel go through the union region, which nothing else uses between two blocks
+                float* part32 = reinterpret_cast<float*>(U);            // [32][C]
+                {
                     const h16* we = wh + bd.ecaw;                       // [ci][co]
-                    const int q4 = C >> 2;
-                    float sacc = 0.0f;
-                    for (int ci0 = p * q4; ci0 < (p + 1) * q4; ci0 += 16) {
-                        h16 wv[16];
+                    constexpr int CG = C >> 3, ROWS = C >> 5;
+                    for (int it = tid; it < 32 * CG; it += 512) {
+                        const int cg = it % CG, p = it / CG;
+                        float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        const h16* wrow = we + (size_t)(p * ROWS) * C + 8 * cg;
+                        half8 w8[ROWS];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) wv[u] = we[(size_t)(ci0 + u) * C + c];
+                        for (int u = 0; u < ROWS; ++u) w8[u] = *reinterpret_cast<const half8*>(wrow + (size_t)u * C);
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) sacc += (float)wv[u] * Mv[ci0 + u];
+                        for (int u = 0; u < ROWS; ++u) {
+                            const float m = Mv[p * ROWS + u];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) s[k] += (float)w8[u][k] * m;
+                        }
+                        float* dst = part32 + p * C + 8 * cg;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) dst[k] = s[k];
                     }
-                    part[p * C + c] = sacc;
                 }
                 __syncthreads();
                 for (int c = tid; c < C; c += 512) {
-                    const float sg = part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c] + wf[bd.ecab + c];
+                    float sg = wf[bd.ecab + c];
+#pragma unroll
+                    for (int p = 0; p < 32; ++p) sg += part32[p * C + c];
                     Mv[c] = fminf(fmaxf(sg * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
                 }
                 __syncthreads();
-                for (int i = tid; i < 64 * C; i += 512) {
-                    const int sq = i / C, cc = i - sq * C;
-                    Xs[sq * ldx + cc] = (h16)((float)Xs[sq * ldx + cc] * Mv[cc]);
+                for (int i = tid; i < 32 * C; i += 512) {               // two adjacent channels per item
+                    const int sq = i / (C >> 1), cc = 2 * (i - sq * (C >> 1));
+                    half2v* px = reinterpret_cast<half2v*>(Xs + sq * ldx + cc);
+                    half2v x2 = *px;
+                    x2[0] = (h16)((float)x2[0] * Mv[cc]); x2[1] = (h16)((float)x2[1] * Mv[cc + 1]);
+                    *px = x2;
                 }
             }
             floatx16 pacc[TPW];                                         // projection accumulators, carried over the chunks
