@@ -714,7 +714,11 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 const int chunk = min(copMax, cop - ch0), ld2 = chunk + 8;
                 // parameter stage of this chunk (the previous chunk's phase 3 no longer reads Pf / Pdw: barrier at its end)
                 for (int i = tid; i < chunk; i += 512) { sb1[i] = wf[bd.b1 + ch0 + i]; sb2[i] = wf[bd.b2 + ch0 + i]; }
-                for (int i = tid; i < chunk * kk * kk; i += 512) Pdw[i] = wh[bd.dw + (size_t)ch0 * kk * kk + i];
+                {   // depthwise taps of the chunk, 16 bytes per lane (offsets and counts are multiples of 8 halfs: chunk % 32 == 0)
+                    const half8* src = reinterpret_cast<const half8*>(wh + bd.dw + (size_t)ch0 * kk * kk);
+                    half8* dst = reinterpret_cast<half8*>(Pdw);
+                    for (int i = tid; i < (chunk * kk * kk) >> 3; i += 512) dst[i] = src[i];
+                }
                 const int copTiles = cop >> 5, tiles = (chunk >> 5) * 2, ct0 = ch0 >> 5;
                 __syncthreads();
                 HM_STAMP();   // parameters staged (+ ECA)
