@@ -153,13 +153,14 @@ def test_policy_command_matches_oracle(hm):
     """UCI::policy (uci.cc:306-393): value / WDL / plies of one forward of the position as the team sees it, and per board the legal
     moves + pass with normalised policy, most probable first; the FEN strings are Board::fen's"""
     moves = ["1e2e4", "2d2d4", "2d7d5", "1d7d5", "1e4d5", "1d8d5", "2e2e4", "2d5e4"]          # captures: pockets are not empty
-    b = _oracle_board(None, moves)
     normal, drop = O.policy_tables("ora")
-    for team, mode in (("white", "go"), ("black", "sit")):
+    promo_fen = "8/P6k/8/8/8/8/8/K7[] w - - 0 1|" + START                                     # a7a8 in all four flavours
+    for team, mode, fen in (("white", "go", None), ("black", "sit", None), ("white", "go", promo_fen)):
+        b = _oracle_board(fen, [] if fen else moves)
         u = hm.Uci(DeviceHashNet(hm), max_nodes=500)
         u.command(f"setoption name Team value {team}")
         u.command(f"setoption name Mode value {mode}")
-        u.command("position startpos moves " + " ".join(moves))
+        u.command("position fen " + fen if fen else "position startpos moves " + " ".join(moves))
         text, _ = u.command("policy")
         t = 0 if team == "white" else 1
         planes = O.planes(b.compact(t, mode == "sit"))
@@ -188,6 +189,8 @@ def test_policy_command_matches_oracle(hm):
                         idx = 0
                     elif kind == 4:
                         idx = drop[stm, m & 63, promo]
+                    elif kind == 3 and promo in (3, 4):
+                        idx = -1                      # rook / bishop promotions have no policy plane (utils.h:183-216): listed with probability 0
                     else:
                         idx = normal[stm, (m >> 6) & 63, m & 63, 1 if (kind == 3 and promo == 2) else 0]
                     logit.append(f(pol)[0][idx] if idx >= 0 else -np.inf)
@@ -198,6 +201,8 @@ def test_policy_command_matches_oracle(hm):
                 at += len(legal)
                 got = {r.strip().split(": ")[0]: float(r.split(": ")[1]) for r in rows}
                 assert set(got) == {O.move_uci(m) for m in legal} and "pass" in got
+                if fen and bd == 0:
+                    assert got["a7a8r"] == got["a7a8b"] == 0.0 and got["a7a8q"] > 0.0 and got["a7a8n"] > 0.0
                 for m, p_ in zip(legal, pr):
                     assert abs(got[O.move_uci(m)] - p_) <= 2e-5 * max(p_, 1e-3), (O.move_uci(m), got[O.move_uci(m)], p_)
                 vals = [float(r.split(": ")[1]) for r in rows]
