@@ -512,6 +512,35 @@ __device__ __forceinline__ floatx16 gemm_tile(floatx16 acc, const h16* xrow, int
     }
     return acc;
 }
+// A wave's tiles of the transposed expand GEMM as ONE fragment stream: tiles tile0, tile0 + tstride, ... (ntile of them), each
+// K = ksteps*16 with ksteps % Q == 0.  The queue is refilled with the next tile's first fragments while the current tile's last
+// group multiplies, so only the first tile pays the weight-fetch latency (the activation fragments are the same for every tile).
+// epi(i, acc) stores tile i.  The last tile's last group re-requests its own first fragments instead of branching.
+template <int Q, typename Epi>
+__device__ __forceinline__ void expand_stream(const h16* xrow, int ksteps, const h16* w, int ntiles, int tile0, int tstride, int ntile, int lane, Epi&& epi) {
+    const frag4* base = reinterpret_cast<const frag4*>(w) + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const frag4* wp = base + (size_t)tile0 * 64;
+    frag4 q[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) q[j] = wp[(size_t)j * ws];
+    for (int i = 0; i < ntile; ++i) {
+        const frag4* wn = base + (size_t)(tile0 + (i + 1 < ntile ? i + 1 : i) * tstride) * 64;
+        floatx16 acc = zero16();
+        for (int b = 0; b < ksteps; b += Q) {
+            const frag4* nx = b + Q < ksteps ? wp + (size_t)(b + Q) * ws : wn;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const frag4 x = lds_frag(xrow + (b + j) * 16);
+                const frag4 f = q[j];
+                q[j] = nx[(size_t)j * ws];
+                acc = mfma(h8(f), h8(x), acc);
+            }
+        }
+        epi(i, acc);
+        wp = wn;
+    }
+}
 // 3x3 convolution as an implicit-im2col GEMM: K = 9*cin, k-step (tap, kk) reads X at act + row(tap) + kk*16 + kh.
 // KPT = cin / 16 k-steps per tap = the depth of the weight-fragment queue (the fragments of tap t+1 are requested while
 // tap t multiplies).
@@ -727,13 +756,28 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                     // (one wave per channel tile for both square halves — every W1 fragment fetched once per workgroup — was
                     // measured: the expand phase went from 12 k to 33 k cycles per chunk; kept: one 32x32 tile per call)
                     const h16* brow = Xs + sqL * ldx + kh;              // tile's square half = t & 1 == stile when t = wave + 8i
-                    for (int t = wave; t < tiles; t += 8) {
-                        const int ct = t >> 1;                          // (t & 1) == (wave & 1) == stile
-                        const floatx16 e = gemm_tile<true, NPF>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+                    // this wave's tiles t = wave, wave + 8, ...: channel tiles (wave >> 1) + 4i, streamed through one fragment queue
+                    // (narrow trunks, K = one queue: the 384-channel variant spills with the streamed form and keeps one call per tile)
+                    if constexpr ((C >> 4) == NPF) {
+                        const int ntile = tiles > wave ? (tiles - wave + 7) >> 3 : 0;
+                        if (ntile > 0)
+                            expand_stream<NPF>(brow, C >> 4, wh + bd.w1, copTiles, ct0 + (wave >> 1), 4, ntile, lane, [&](int i, const floatx16& e) {
+                                const int ct = (wave >> 1) + 4 * i;
 #pragma unroll
-                        for (int rg = 0; rg < 16; ++rg) {
-                            const int ch = ct * 32 + drow(rg, lane);
-                            Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+                                for (int rg = 0; rg < 16; ++rg) {
+                                    const int ch = ct * 32 + drow(rg, lane);
+                                    Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+                                }
+                            });
+                    } else {
+                        for (int t = wave; t < tiles; t += 8) {
+                            const int ct = t >> 1;                      // (t & 1) == (wave & 1) == stile
+                            const floatx16 e = gemm_tile<true, NPF>(zero16(), brow, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+#pragma unroll
+                            for (int rg = 0; rg < 16; ++rg) {
+                                const int ch = ct * 32 + drow(rg, lane);
+                                Y1[ch * 66 + sqL] = (h16)fmaxf(e[rg] + sb1[ch], 0.0f);
+                            }
                         }
                     }
                 }
@@ -751,6 +795,8 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
                 __syncthreads();
                 HM_STAMP();   // depthwise done
                 // phase 3 — 1x1 project, K = this chunk's channels: k-steps ch0/16 .. of W2
+                // (streaming a wave's TPW tiles through one fragment queue, as the narrow expand phase does, was measured on the
+                // 384-channel variant: 108 spilled VGPRs instead of 42; kept: one call per tile)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const int ctile = (wave + 8 * i) >> 1;
