@@ -20,7 +20,7 @@
 
 namespace hmd {
 
-struct RulesTab {
+struct alignas(16) RulesTab {
     AttackTab att;
     ZobristTab zob;
     u64 z_promoted[64];     // repetition-key marks for promoted pieces ('~' in the reference's FEN key)
