@@ -59,9 +59,17 @@ __device__ __forceinline__ int pop_lsb(u64& b) { int s = lsb(b); b &= b - 1; ret
 // Cooperative global->LDS copy of a POD table (8-byte granules).
 template <typename T>
 __device__ __forceinline__ void stage_table(T* lds, const T* g) {
-    // 16 bytes per lane, four requests of a thread in flight before the first is stored: the 12.5 KB rules table is one round trip
-    // for a 256-thread block instead of six (6.7 k -> ~1.5 k cycles at the top of every k_collect / k_process)
+    const u64* src = reinterpret_cast<const u64*>(g);
+    u64* dst = reinterpret_cast<u64*>(lds);
+    for (unsigned i = threadIdx.x; i < sizeof(T) / 8; i += blockDim.x) dst[i] = src[i];
+}
+// The same with 16 bytes per lane and a thread's four requests in flight before the first is stored: the 12.5 KB rules table is
+// one round trip for a 256-thread block instead of six (the lockstep kernels stage it at the top of every launch).  Costs 16
+// VGPRs, which the occupancy-bound kernels (perft: 2.75 -> 4.2 s with this form) cannot spare: they keep the plain copy.
+template <typename T>
+__device__ __forceinline__ void stage_table_wide(T* lds, const T* g) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(T) % 16 == 0 && alignof(T) >= 16, "16-byte aligned table");
     constexpr unsigned N16 = sizeof(T) / 16;
     const u32x4* src = reinterpret_cast<const u32x4*>(g);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
@@ -71,10 +79,6 @@ __device__ __forceinline__ void stage_table(T* lds, const T* g) {
         for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * blockDim.x; if (i < N16) v[u] = src[i]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * blockDim.x; if (i < N16) dst[i] = v[u]; }
-    }
-    if constexpr (sizeof(T) % 16 != 0) {                               // 8-byte tail (every table is a multiple of 8 bytes)
-        static_assert(sizeof(T) % 8 == 0, "tables are built from 8-byte words");
-        if (threadIdx.x == 0) reinterpret_cast<u64*>(lds)[sizeof(T) / 8 - 1] = reinterpret_cast<const u64*>(g)[sizeof(T) / 8 - 1];
     }
 }
 

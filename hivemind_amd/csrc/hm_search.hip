@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     Game* const gGame = s.g;
     Node* const gNodes = s.nodes;
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
-    stage_table(&s_rt, pl.rules);
+    stage_table_wide(&s_rt, pl.rules);
     {
         const bool alt = gGame->pwSel != 0;                      // this game's progressive-widening profile
         const int* pwr = alt ? pl.pwRootAlt : pl.pwRoot;
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params p
         }
         atomicMin(&ck->pStart, (u64)__builtin_amdgcn_s_memrealtime());
     }
-    stage_table(&s_rt, pl.rules);
+    stage_table_wide(&s_rt, pl.rules);
     __syncthreads();
     G s = make_view(pl, prm, blockIdx.x);
     process_step(s, s_rt, s_exp, out, blockIdx.x, activeCount);
