@@ -289,6 +289,30 @@ def test_tree_reuse_falls_back_when_the_pool_is_full(hm):
     u.close()
 
 
+def test_timed_searches_reuse_the_tree_with_a_shrunk_budget(hm):
+    """a time-limited search asks for the whole pool; with a retained tree in it the budget shrinks to what still fits behind the
+    retained nodes (hm_sp_set_tree_reuse mode 2) or, when less than half would fit, the search starts from an empty pool — either way
+    it answers and never overflows the pool"""
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=1200)
+    moves = ["1e2e4", "2d2d4"]
+    reused = 0
+    for step in range(5):
+        u.command("position startpos moves " + " ".join(moves))
+        text, _ = u.command("go movetime 40")
+        assert "search failed" not in text and "overflow" not in text, text
+        lines = text.strip().split("\n")
+        reused += any(l.startswith("info string Tree reuse") for l in lines)
+        best = re.match(r"bestmove (\(\S+\))(?: ponder (\(\S+\)))?", lines[-1])
+        assert best, lines
+        info = [l for l in lines if l.startswith("info depth")][-1]
+        assert int(re.search(r" nodes (\d+) ", info).group(1)) <= 1200 * 1.05 + 16
+        moves += _tokens(best.group(1)) + (_tokens(best.group(2)) if best.group(2) else [])
+        if not best.group(2):
+            break
+    assert reused >= 1, "no search of the sequence started from the retained tree"
+    u.close()
+
+
 def _wait_for_bestmove(u, limit_s=20.0):
     import time
     text, t0 = "", time.time()
