@@ -10,10 +10,17 @@ rank 0, inside the timed region) -> weak scaling.
 
 `--workload planes` keeps the round-1 first bench (configs[1], batched plane-encode of 65 536
 positions); its numbers are also reported under "extra" of the default run, with joint perft.
+
+`--gpus N` without a torchrun environment (WORLD_SIZE unset): this process is only a launcher.  Before any
+GPU / HIP call it starts N children of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+the device-list shape of the reference's main.cc:154-173), forwards rank 0's JSON line and exits non-zero if
+any child fails.  Under torchrun (WORLD_SIZE set) every process is a rank, as before.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -126,12 +133,76 @@ PMC_SELFPLAY = "profiles/r02_selfplay64_pmc_hbm.json"
 PMC_PLANES = "profiles/r02_planes_pmc_hbm.json"
 
 
+def launch_ranks(n, argv):
+    """Parent of a `--gpus N` run started without torchrun: N child ranks of this script, one per GPU.  Nothing here touches
+    the GPU (no HIP call, no torch.cuda query), so no process that initialised a device is ever replaced or forked."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.05)
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
+    if failed is not None:                      # a dead rank leaves the others waiting in a collective: end exactly our children
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    if failed is not None or any(codes):
+        print(f"bench.py: rank {failed[0] if failed else '?'} failed (exit codes {codes})", file=sys.stderr)
+        return 1
+    return 0
+
+
+def bench_stub(steps, warmup, rank, world, dist):
+    """Launcher / collective rehearsal without a GPU (tests/test_host_logic.py): the timing protocol of the real workloads
+    (barrier, K timed steps, max over ranks, sum of the units) around a trivial CPU step."""
+    import torch as T
+
+    def allred(x, op):
+        if dist is None:
+            return x
+        t = T.tensor([x], dtype=T.float64)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+    if os.environ.get("HM_BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    for _ in range(warmup):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(steps):
+        time.sleep(0.002)
+        units += 10 + rank
+    if dist is not None:
+        dist.barrier()
+    dt = allred(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
+    units = allred(units, dist.ReduceOp.SUM if dist else None)
+    return dict(metric="stub units/sec (launcher rehearsal, no GPU)", value=units / dt, unit="units/s", steps=steps, warmup=warmup,
+                ms_per_step=dt / steps * 1e3, dtype="none", config={"workload": "stub"}, roofline=None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="selfplay", choices=["selfplay", "planes"])
+    ap.add_argument("--workload", default="selfplay", choices=["selfplay", "planes", "stub"])
     ap.add_argument("--games", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=400)
     ap.add_argument("--model", default="small", choices=["small", "full"])
@@ -139,6 +210,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,14 +223,26 @@ def main():
     backend = os.environ.get("HM_BENCH_BACKEND", "nccl")
     if os.environ.get("HM_BENCH_SHARE_GPU"):
         local = 0
+    if args.workload == "stub":
+        backend = "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
+        if args.workload != "stub":
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if args.workload == "stub":
+        line = bench_stub(args.steps, args.warmup, rank, world, dist)
+        if rank == 0:
+            line.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                         "cpu_baseline": None, "extra": {}})
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import hivemind_amd as hm
     from hivemind_amd import net as N

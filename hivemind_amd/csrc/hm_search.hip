@@ -57,10 +57,12 @@ constexpr int BATCH = 8;                 // SearchParams::BATCH_SIZE
 constexpr int MAX_TRAJ = 96;             // search path cap (root .. leaf)
 constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown to the run's macro-ply limit, hm_sp_create_ex)
 constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
-constexpr int MAX_VISITS_TAB = 1 << 15;  // cpuct / PW tables
+constexpr int MIN_VISITS_TAB = 1 << 15;  // cpuct / PW tables: at least this long; sized from the node budget (Params::tabLen)
 constexpr int NLISTS = 8;                // LDS scratch move lists per wave
 constexpr int COLLECT_THREADS = 256;     // k_collect: traversal wave, classifier wave, plane-writer wave, generator wave
 constexpr float Q_INIT = -1.0f;
+constexpr int LDS_DIRTY_BITS = 2048;      // k_collect's LDS node mirror: dirty bits, hence the largest mirrored pool
+static_assert(LDS_DIRTY_BITS / 32 <= COLLECT_THREADS, "s_dirty is cleared by one pass of the block");
 
 enum : uint8_t { T_UNSOLVED = 0, T_WIN = 1, T_LOSS = 2, T_DRAW = 3 };
 enum : uint8_t { F_PENDING = 1, F_EXPANDED = 2 };
@@ -135,6 +137,7 @@ struct Game {
 
 struct Params {          // device-visible configuration + pool geometry
     int nGames, nodeCap, ttCap;        // ttCap power of two
+    int tabLen;                        // entries of the cpuct / progressive-widening tables (visit counts beyond clamp to the last one)
     int histGame, histCap;             // per-board history keys: game part / game + search path
     int ldsNodes;                      // k_collect keeps the game's node pool in LDS (nodeCap * 64 B fits beside its other LDS)
     u32 arenaCap;                      // 8-byte units
@@ -162,8 +165,8 @@ struct Pools {
     float* noise;         // [nGames][2][NOISE_CAP]
     u32* leafMoves;       // [nGames][2 batches][BATCH rows][2 boards][HM_MAX_MOVES]: filtered legal lists of the network leaves
     int* leafCounts;      // [nGames][2][BATCH][2]
-    const float* cpuctTab;   // [MAX_VISITS_TAB]
-    const int* pwRoot;       // [MAX_VISITS_TAB]
+    const float* cpuctTab;   // [Params::tabLen]
+    const int* pwRoot;       // [Params::tabLen]
     const int* pwNode;
     const int* pwRootAlt;    // second schedule (tournaments give each network its own PW coefficient, tournament.h:30-41)
     const int* pwNodeAlt;
@@ -482,7 +485,7 @@ __device__ inline bool should_expand_new_child(G& s, const Node& n, const EdgeSc
     if (sc.anyUnvisited) return false;
     int v = n.visits + n.vvsum;
     if (v < 0) v = 0;
-    if (v >= MAX_VISITS_TAB) v = MAX_VISITS_TAB - 1;
+    if (v >= s.prm->tabLen) v = s.prm->tabLen - 1;
     const int allowed = n.depth == 0 ? pw_root_of(s, v) : pw_node_of(s, v);
     return hasNext && n.expanded < allowed;
 }
@@ -595,7 +598,7 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
     Edge* e = edges_of(s, n);
     const int visits = sc.visits;
     const float sqrtVisits = sqrtf((float)visits);
-    int vi = visits < 0 ? 0 : (visits >= MAX_VISITS_TAB ? MAX_VISITS_TAB - 1 : visits);
+    int vi = visits < 0 ? 0 : (visits >= s.prm->tabLen ? s.prm->tabLen - 1 : visits);
     const float c = cpuct_of(s, vi);
     const float explorationBase = c * sqrtVisits;
     const bool hasNonLosing = sc.anyNonLosing && n.type == T_UNSOLVED;
@@ -1552,7 +1555,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     constexpr int TABN = 512;                                      // visits beyond this read the tables in HBM
     __shared__ float s_cpuct[TABN];
     __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
-    __shared__ u32 s_dirty[64];                                    // 2048 node bits: more than the largest pool the mirror admits
+    __shared__ u32 s_dirty[LDS_DIRTY_BITS / 32];                   // one bit per mirrored node (hm_sp_create_ex admits the mirror only for pools this small)
     static_assert(sizeof(Game) % 4 == 0 && sizeof(Node) == 64, "LDS mirrors are copied in 4 / 16 byte words");
     PROF_INIT();
     PROF_T(ta);
@@ -1571,7 +1574,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
     }
     if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
-    if (threadIdx.x < 64) s_dirty[threadIdx.x] = 0;
+    if (threadIdx.x < LDS_DIRTY_BITS / 32) s_dirty[threadIdx.x] = 0;
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
     const int startCount = s_game.nodeCount;                       // nodes with a higher id are created by this launch
@@ -2347,6 +2350,7 @@ struct hm_sp {
     std::vector<u64> h_rootHash;
     float pwExponent = 0.4f, altPw = -1.0f, altRootPw = -1.0f;
     int *d_pwRootAlt = nullptr, *d_pwNodeAlt = nullptr;
+    size_t ldsMirrorMax = 0;               // LDS left beside k_collect's static LDS (the largest node mirror a CU admits)
     // Per-ply traffic with the host goes through two pinned staging blocks and contiguous device blocks: one copy per call
     // and direction instead of one per array (a pageable hipMemcpy costs tens of microseconds before the first byte moves).
     unsigned char* h_stage = nullptr;      // pinned
@@ -2431,7 +2435,9 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
         if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_collect)) == hipSuccess) staticLds = fa.sharedSizeBytes;
         else (void)hipGetLastError();
         const size_t room = staticLds < 160 * 1024 ? 160 * 1024 - staticLds : 0;
-        p.ldsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+        // (s_dirty in k_collect holds LDS_DIRTY_BITS node bits: pools beyond that walk their nodes in place)
+        p.ldsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && p.nodeCap <= LDS_DIRTY_BITS && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+        sp->ldsMirrorMax = room;
     }
     int tt = 64;
     while (tt < 4 * p.nodeCap) tt <<= 1;
@@ -2441,7 +2447,9 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     p.wdlWeight = c.wdl_value_weight; p.mlDiscount = c.moves_left_discount;
     p.enableTranspositions = c.enable_transpositions; p.enableDynamicFpu = c.enable_dynamic_fpu; p.enableWdl = c.enable_wdl_eval;
     p.qVetoDelta = 0.4f; p.qValueWeight = 1.0f;
-    if (p.ldsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)p.nodeCap * sizeof(Node))) != hipSuccess) {
+    // the attribute is per-function process state: always the largest mirror the CU admits, so that a second, smaller engine does
+    // not lower the limit under an engine that is still alive
+    if (p.ldsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->ldsMirrorMax) != hipSuccess) {
         (void)hipGetLastError();
         p.ldsNodes = 0;                                            // walk the pool in place
     }
@@ -2462,27 +2470,32 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     rc |= dalloc(sp, &pl.leafCounts, G_ * 2 * BATCH * 2);
     if (rc) { hm_sp_destroy(sp); return rc; }
     // cpuct(N) and the PW schedule from the reference's own float expressions (search_params.h:307-317)
-    std::vector<float> cp(MAX_VISITS_TAB);
-    std::vector<int> pr(MAX_VISITS_TAB), pn(MAX_VISITS_TAB);
-    for (int v = 0; v < MAX_VISITS_TAB; ++v) {
+    // A node's visit count is bounded by the simulations of the searches its tree has lived through (tree reuse carries visits over
+    // from one `go` to the next), so the tables are sized from the node budget: a UCI engine with max_nodes = 100 000 reaches root
+    // visits far beyond 32 768, where a clamped table would freeze cpuct and stop the root from widening (search_params.h:307-317
+    // evaluate both at the true N).
+    const int TAB = p.tabLen = (int)std::min<long long>(std::max<long long>(MIN_VISITS_TAB, 8LL * max_nodes + 4096), 1LL << 24);
+    std::vector<float> cp(TAB);
+    std::vector<int> pr(TAB), pn(TAB);
+    for (int v = 0; v < TAB; ++v) {
         cp[v] = std::log(((float)v + c.cpuct_base + 1.0f) / c.cpuct_base) + c.cpuct_init;
         auto allowed = [&](float coef) { return v <= 0 ? 1 : (int)std::ceil(coef * std::pow((float)v, c.pw_exponent)); };
         pr[v] = allowed(c.root_pw_coefficient);
         pn[v] = allowed(c.pw_coefficient);
     }
     float* dcp; int *dpr, *dpn;
-    rc |= dalloc(sp, &dcp, MAX_VISITS_TAB); rc |= dalloc(sp, &dpr, MAX_VISITS_TAB); rc |= dalloc(sp, &dpn, MAX_VISITS_TAB);
+    rc |= dalloc(sp, &dcp, TAB); rc |= dalloc(sp, &dpr, TAB); rc |= dalloc(sp, &dpn, TAB);
     if (rc) { hm_sp_destroy(sp); return rc; }
-    (void)hipMemcpy(dcp, cp.data(), sizeof(float) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
-    (void)hipMemcpy(dpr, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
-    (void)hipMemcpy(dpn, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dcp, cp.data(), sizeof(float) * TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpr, pr.data(), sizeof(int) * TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dpn, pn.data(), sizeof(int) * TAB, hipMemcpyHostToDevice);
     pl.cpuctTab = dcp; pl.pwRoot = dpr; pl.pwNode = dpn;
     // the alternate schedule has its own tables from the start (kernel arguments captured in a HIP graph keep these pointers);
     // hm_sp_set_pw_profiles rewrites their contents
-    rc |= dalloc(sp, &sp->d_pwRootAlt, MAX_VISITS_TAB); rc |= dalloc(sp, &sp->d_pwNodeAlt, MAX_VISITS_TAB);
+    rc |= dalloc(sp, &sp->d_pwRootAlt, TAB); rc |= dalloc(sp, &sp->d_pwNodeAlt, TAB);
     if (rc) { hm_sp_destroy(sp); return rc; }
-    (void)hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
-    (void)hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * TAB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * TAB, hipMemcpyHostToDevice);
     pl.pwRootAlt = sp->d_pwRootAlt; pl.pwNodeAlt = sp->d_pwNodeAlt;
     sp->pwExponent = c.pw_exponent;
     pl.rules = g_rules_dev; pl.polNormal = g_polN_dev; pl.polDrop = g_polD_dev;
@@ -2536,14 +2549,15 @@ int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw
     if (!(alt_pw_coefficient > 0.0f) || !(alt_root_pw_coefficient > 0.0f) || !std::isfinite(alt_pw_coefficient) || !std::isfinite(alt_root_pw_coefficient))
         return hm_fail(HM_ERR_INVALID, "PW coefficients must be positive and finite");
     if (alt_pw_coefficient != sp->altPw || alt_root_pw_coefficient != sp->altRootPw) {
-        std::vector<int> pr(MAX_VISITS_TAB), pn(MAX_VISITS_TAB);
-        for (int v = 0; v < MAX_VISITS_TAB; ++v) {
+        const int TAB = sp->prm.tabLen;
+        std::vector<int> pr(TAB), pn(TAB);
+        for (int v = 0; v < TAB; ++v) {
             auto allowed = [&](float coef) { return v <= 0 ? 1 : (int)std::ceil(coef * std::pow((float)v, sp->pwExponent)); };
             pr[v] = allowed(alt_root_pw_coefficient);
             pn[v] = allowed(alt_pw_coefficient);
         }
-        HIPCHK(hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * MAX_VISITS_TAB, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sp->d_pwRootAlt, pr.data(), sizeof(int) * TAB, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sp->d_pwNodeAlt, pn.data(), sizeof(int) * TAB, hipMemcpyHostToDevice));
         sp->altPw = alt_pw_coefficient; sp->altRootPw = alt_root_pw_coefficient;
     }
     HIPCHK(hipMemcpy(sp->d_mask, profiles, sp->nGames, hipMemcpyHostToDevice));

@@ -416,28 +416,28 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         hipEvent_t* y = &s->sync[(size_t)(iters % RING) * 2];
         hipEvent_t* yPrev = &s->sync[(size_t)((iters + RING - 1) % RING) * 2];
         const bool poll = iters >= noPollBefore || (iters - harvested) >= RING - 2;
-        const bool timed = is_timed(iters);
+        const bool evTimed = is_timed(iters);          // leg events around this iteration (callback evaluator only); `timed` above = movetime search
         if (native) {
             // tree stream: collect(next) -- net stream: forward(cur) -- tree stream: process(cur)
             void* hv[2][5] = {{s->io.value, s->io.pi_a, s->io.pi_b, s->io.wdl, s->io.moves_left},
                               {s->io.value_2, s->io.pi_a_2, s->io.pi_b_2, s->io.wdl_2, s->io.moves_left_2}};
             void** h = hv[iters & 1];
-            if (timed) (void)hipEventRecord(e[0], s->sT);
+            if (evTimed) (void)hipEventRecord(e[0], s->sT);
             if (int rc = collect_rows(s, 1 - which)) return rc;
-            if (timed) (void)hipEventRecord(e[1], s->sT);
+            if (evTimed) (void)hipEventRecord(e[1], s->sT);
             // planes[which] were completed by the previous iteration's collect.  The forward could start
             // right after it, but measured on MI355X it then shares CUs with k_process (8-wave blocks,
             // 79 KB LDS), which stretches from 0.12 to 0.33 ms and lengthens the critical path; so the
             // forward is ordered behind process(i-1) and overlaps only collect(i).
             if (iters > 0) (void)hipStreamWaitEvent(s->sN, yPrev[1], 0);
-            if (timed) (void)hipEventRecord(e[2], s->sN);
+            if (evTimed) (void)hipEventRecord(e[2], s->sN);
             if (int rc = forward_rows(s, which, h, allRows)) return rc;
-            if (timed) (void)hipEventRecord(e[3], s->sN);
+            if (evTimed) (void)hipEventRecord(e[3], s->sN);
             (void)hipEventRecord(y[0], s->sN);
             (void)hipStreamWaitEvent(s->sT, y[0], 0);
-            if (timed) (void)hipEventRecord(e[4], s->sT);
+            if (evTimed) (void)hipEventRecord(e[4], s->sT);
             if (int rc = hm_sp_process(s->sp, h[0], h[1], h[2], h[3], h[4], nullptr, s->sT)) return rc;
-            if (timed) (void)hipEventRecord(e[5], s->sT);
+            if (evTimed) (void)hipEventRecord(e[5], s->sT);
             (void)hipEventRecord(y[1], s->sT);
             if (poll || timed) {
                 if (int rc = hm_sp_active_on(s->sp, s->hActive, s->sT)) return rc;     // async copy + stream sync

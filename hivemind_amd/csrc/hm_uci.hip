@@ -486,16 +486,11 @@ static void uci_go(hm_uci* u, std::istringstream& is) {   // uci.cc:143-231
     }
     uci_stop(u);
     if (gp.nodes == 0 && gp.moveTime <= 0) gp.moveTime = 1000;                      // "Default to 1 second if nothing specified"
-    if (!gp.ponder) {                                        // the command returns when bestmove has been printed
-        std::string text;
-        uci_search(u, gp, text);
-        std::lock_guard<std::mutex> lock(u->mu);
-        u->out += text;
-        return;
-    }
-    // ponder search: runs on a worker thread until `ponderhit` (then its budget applies) or `stop`; the text is fetched with later
-    // commands (an empty line polls)
-    u->pondering.store(true, std::memory_order_release);
+    // Every search runs on the worker thread (mainSearchThread of the reference, uci.cc:192-205): the command returns at once, so
+    // `stop`, `isready`, `ponderhit` and `quit` reach a running search; its text (info lines, bestmove) is fetched with later
+    // commands (an empty line polls, hm_uci_busy tells whether it is still running).  A ponder search ignores its budget until
+    // `ponderhit`; an ordinary one applies it from the start.
+    u->pondering.store(gp.ponder, std::memory_order_release);
     int dev = 0;
     (void)hipGetDevice(&dev);
     u->busy.store(true, std::memory_order_release);
@@ -680,7 +675,7 @@ int64_t hm_uci_command(hm_uci* u, const char* line, char* out, int64_t cap) {
     return quit ? HM_UCI_QUIT : n;
 }
 
-// 1 while a `go ponder` search is running on its worker thread (its text arrives with later commands; an empty line polls).
+// 1 while a search (`go ...`) is running on its worker thread (its text arrives with later commands; an empty line polls).
 int hm_uci_busy(hm_uci* u) { return u && u->busy.load(std::memory_order_acquire) ? 1 : 0; }
 
 // Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text

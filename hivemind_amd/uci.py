@@ -72,8 +72,7 @@ class Uci:
         check(lib.hm_uci_create(net.handle if native else None, C.byref(self.io), self._cb, None, int(max_nodes), C.byref(self.h)))
         self._buf = C.create_string_buffer(1 << 16)
 
-    def command(self, line: str):
-        """-> (output text, quit flag)"""
+    def _call(self, line: str):
         n = lib.hm_uci_command(self.h, line.encode(), self._buf, len(self._buf))
         if self._error is not None:
             err, self._error = self._error, None
@@ -83,8 +82,24 @@ class Uci:
             n = lib.hm_uci_command(self.h, b"", self._buf, len(self._buf))
         return self._buf.value.decode() if n != 0 else "", n == UCI_QUIT
 
+    def command(self, line: str, wait: bool = True):
+        """-> (output text, quit flag).  The C ABI never blocks on a search (`go` starts it on the engine's worker thread);
+        with wait=True an ordinary `go` is followed here until its bestmove has been printed, which is what scripts and tests
+        want.  `go ponder` always returns at once (it ends with `ponderhit` / `stop`); the stdin loop passes wait=False."""
+        text, quit_ = self._call(line)
+        tok = line.split()
+        if wait and tok and tok[0] == "go" and "ponder" not in tok:
+            import time
+            while self.busy():
+                time.sleep(0.0005)                               # releases the GIL: a callback evaluator runs on the worker thread
+                more, _ = self._call("")
+                text += more
+            more, _ = self._call("")
+            text += more
+        return text, quit_
+
     def busy(self) -> bool:
-        """a `go ponder` search is still running (poll its text with command(""))"""
+        """a search is still running on the engine's worker thread (poll its text with command(""))"""
         return bool(lib.hm_uci_busy(self.h))
 
     def board(self):
@@ -117,21 +132,31 @@ def main(argv=None):
     torch.manual_seed(0)
     model = N.load_checkpoint(a.checkpoint) if a.checkpoint else (N.rise_v3_small() if a.model == "small" else N.rise_v33())
     uci = Uci(N.FusedNet(model), a.max_nodes)
-    import select
+    import queue
+    import threading
 
     def emit(text):
         if text:
             sys.stdout.write(text)
             sys.stdout.flush()
+    # stdin is read on its own thread, line by line, into a queue: the loop below never mixes select() on the descriptor with
+    # Python's buffered readline (two commands arriving in one pipe write would leave the second in the buffer, unseen by select)
+    lines = queue.Queue()
+
+    def reader():
+        for ln in sys.stdin:
+            lines.put(ln)
+        lines.put(None)
+    threading.Thread(target=reader, daemon=True).start()
     while True:
-        # a ponder search prints when it ends (after ponderhit / stop): poll its text between input lines
-        if uci.busy() and not select.select([sys.stdin], [], [], 0.005)[0]:
-            emit(uci.command("")[0])
+        try:
+            line = lines.get(timeout=0.005 if uci.busy() else None)
+        except queue.Empty:
+            emit(uci.command("", wait=False)[0])                 # a running search prints as it goes / when it ends
             continue
-        line = sys.stdin.readline()
-        if not line:
-            break
-        text, quit_ = uci.command(line.strip())
+        if line is None:
+            line = "quit"                                        # end of input is `quit` (uci.cc:399-401), which stops a running search
+        text, quit_ = uci.command(line.strip(), wait=False)
         emit(text)
         if quit_:
             break

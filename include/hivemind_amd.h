@@ -88,7 +88,13 @@ enum { HM_DT_F16 = 0, HM_DT_F32 = 1, HM_DT_U8 = 2 };
 
 /* Builds attack/Zobrist/policy tables on the host and uploads them to the
  * current HIP device.  Replaces the start-up sequence of main.cc:75-81
- * (Bitboards::init, Position::init, init_policy_index).  Idempotent. */
+ * (Bitboards::init, Position::init, init_policy_index).  Idempotent.
+ * Process model: ONE process per GPU.  The rule / policy-index tables are
+ * process-wide device allocations made on the device that was current at
+ * the first hm_init; the reference's "one process, a list of devices"
+ * shape (main.cc:154-173) maps to one rank per device (bench.py --gpus N
+ * starts them; torchrun does the same), not to one process driving several
+ * devices, which this library does not support. */
 int hm_init(int device);
 /* Message of the last failure on this thread (never NULL). */
 const char* hm_last_error(void);
@@ -501,9 +507,12 @@ int hm_move_uci(hm_move move, char* out, int cap);
 /* reference's early exit / early stopping / time extension rules; final    */
 /* `info` lines with MultiPV principal variations (agent.cc:917-965,        */
 /* 1218-1290) and `bestmove ... ponder ...` (agent.cc:1054-1113).           */
-/* `go ponder ...` searches on a worker thread until `ponderhit` (then the  */
-/* budget applies) or `stop`; the tree is reused from one `go` to the next   */
-/* (agent.cc:1345-1451) until `ucinewgame`.                                 */
+/* Every `go` searches on a worker thread (mainSearchThread, uci.cc:192-205): */
+/* hm_uci_command returns at once, `stop` / `isready` / `quit` reach a running */
+/* search, its text is fetched with later commands while hm_uci_busy() is 1.   */
+/* `go ponder ...` ignores its budget until `ponderhit` (then it applies) or   */
+/* `stop`; the tree is reused from one `go` to the next (agent.cc:1345-1451)   */
+/* until `ucinewgame`.                                                       */
 /* ================================================================== */
 typedef struct hm_uci hm_uci;
 #define HM_UCI_QUIT (-1000000)
@@ -511,11 +520,12 @@ typedef struct hm_uci hm_uci;
  * io: caller-owned device buffers for 8 rows (planes[2], five heads); max_nodes: largest node budget of a `go`. */
 int hm_uci_create(const hm_net* net, const hm_eval_io* io, hm_eval_fn fn, void* user, int max_nodes, hm_uci** out);
 /* One command line in, the engine's output text out (several lines possible).  Returns the text length, -(needed size)
- * when cap is too small (the command HAS run; call again with "" to fetch the text) and HM_UCI_QUIT for `quit`. */
+ * when cap is too small (the command HAS run; call again with "" to fetch the text) and HM_UCI_QUIT for `quit`.
+ * `go` only starts the search: poll with "" until hm_uci_busy() is 0 to collect its `info` / `bestmove` lines. */
 int64_t hm_uci_command(hm_uci* uci, const char* line, char* out, int64_t cap);
 /* The current game position (after the last `position`), team / time_adv = the Team / Mode options. */
 int hm_uci_board(hm_uci* uci, hm_board* out);
-/* 1 while a `go ponder` search is running (its text arrives with later commands; an empty line polls). */
+/* 1 while a search is running on the worker thread (its text arrives with later commands; an empty line polls). */
 int hm_uci_busy(hm_uci* uci);
 /* Board::fen(board) (environment/board.h:172-174 -> Position::fen(false, true)) of a compact board; host-only.  Returns the text
  * length, or -(needed size) when cap is too small. */

@@ -106,3 +106,23 @@ def test_tournament_with_a_movetime_limit(hm):
     # a node budget and a move time together are refused (tournament.cc:338-341)
     with pytest.raises(hm.HivemindError, match="exactly one positive nodes or movetime"):
         hm.Tournament(hm.default_tournament_config(games=2, nodes=100, move_time_ms=10), contender=a, baseline=b)
+
+
+def test_movetime_is_enforced_without_the_step_graph(hm, monkeypatch):
+    """The eager lockstep loop (no captured graph: HM_SELFPLAY_NO_GRAPH, or a failed capture) must poll the slots' time controllers
+    too: with a pool of 60 000 nodes per search, a search that ignored the clock would run ~150 x the move time."""
+    import time
+    from hivemind_amd import net as N
+    monkeypatch.setenv("HM_SELFPLAY_NO_GRAPH", "1")
+    torch.manual_seed(0)
+    a = N.FusedNet(N.rise_v3_small())
+    move_ms, plies = 40, 4
+    cfg = hm.default_tournament_config(games=2, nodes=0, move_time_ms=move_ms, max_macro_plies=plies, seed=5, concurrent_games=2, max_search_nodes=60000)
+    t = hm.Tournament(cfg, contender=a, baseline=a)
+    t0 = time.time()
+    res = t.run()
+    dt = time.time() - t0
+    t.close()
+    assert res.games == 2 and 2 <= res.searched_positions <= 2 * plies
+    assert dt < plies * (move_ms * 2.25 + 60) * 1e-3 + 2.0, dt
+    assert res.total_nodes / res.searched_positions < 30000

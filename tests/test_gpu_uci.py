@@ -401,3 +401,61 @@ def test_go_movetime_returns_a_legal_best_move(hm):
     assert len(infos) >= 2 and depths[:-1] == sorted(set(depths[:-1])) and depths[-1] >= depths[-2], depths
     assert all(" pv (" in l for l in infos)
     u.close()
+
+
+def test_stop_and_isready_reach_an_ordinary_search(hm):
+    """Every `go` runs on the engine's worker thread (mainSearchThread, uci.cc:192-205): the C ABI returns at once, `isready` is
+    answered while the search runs, `stop` ends a long `go movetime` promptly (UCI::stop, uci.cc:64-75) and bestmove follows."""
+    import time
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=100000)
+    u.command("position startpos moves 1e2e4 2d2d4")
+    u.command("go nodes 64")                                                # warm-up (first launches of the process)
+    t0 = time.perf_counter()
+    assert u.command("go movetime 60000", wait=False) == ("", False)
+    assert time.perf_counter() - t0 < 1.0 and u.busy()
+    assert u.command("isready")[0].endswith("readyok\n") and u.busy()       # the search goes on
+    time.sleep(0.05)
+    text, _ = u.command("stop")
+    assert time.perf_counter() - t0 < 10.0 and not u.busy()
+    assert re.match(r"bestmove \((\S+),(\S+)\)", text.strip().split("\n")[-1]), text
+    # and a node-limited one, stopped long before its budget
+    assert u.command("go nodes 90000", wait=False) == ("", False)
+    time.sleep(0.05)
+    text, _ = u.command("stop")
+    nodes = int(re.search(r" nodes (\d+) ", [l for l in text.split("\n") if l.startswith("info depth")][-1]).group(1))
+    assert nodes < 90000 and text.strip().split("\n")[-1].startswith("bestmove ("), text
+    u.close()
+
+
+def test_cli_loop_sees_two_commands_written_at_once():
+    """the stdin loop of `python -m hivemind_amd.uci`: `go ponder ...` and `ponderhit` arriving in ONE pipe write must both be
+    seen (a select() on the descriptor next to a buffered readline would leave the second line unseen and never print bestmove)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.Popen([sys.executable, "-m", "hivemind_amd.uci", "--model", "small", "--max-nodes", "4000"], cwd=root,
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    import queue
+    import threading
+    got = queue.Queue()
+    threading.Thread(target=lambda: [got.put(l) for l in iter(p.stdout.readline, b"")], daemon=True).start()
+    try:
+        p.stdin.write(b"position startpos moves 1e2e4 2d2d4\ngo ponder nodes 64\nponderhit\n")
+        p.stdin.flush()
+        best = None
+        try:
+            while best is None:                                             # nothing else is written until bestmove has arrived
+                line = got.get(timeout=180).decode()
+                if line.startswith("bestmove ("):
+                    best = line
+        except queue.Empty:
+            pass
+        p.stdin.write(b"quit\n")
+        p.stdin.flush()
+        p.wait(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert best is not None, p.stderr.read().decode()[-2000:]
+    assert p.returncode == 0

@@ -132,3 +132,32 @@ def test_reference_shaped_state_dict_and_checkpoint_load(tmp_path):
     torch.save({"model_state_dict": bad}, tmp_path / "bad.tar")
     with pytest.raises(RuntimeError, match="Missing key"):
         N.load_checkpoint(str(tmp_path / "bad.tar"))
+
+
+def _bench(args, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=120)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts two ranks before anything touches a GPU and
+    forwards rank 0's line (the device-list shape of the reference's main.cc:154-173); stub workload, gloo, no GPU."""
+    import json
+    r = _bench(["--gpus", "2", "--workload", "stub", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    # value is the whole-job aggregate: both ranks' units (10 and 11 per step) over the slowest rank's time
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 21.0) < 1e-6
+    one = json.loads([l for l in _bench(["--workload", "stub"]).stdout.splitlines() if l.startswith("{")][0])
+    assert one["n_gpus"] == 1
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    r = _bench(["--gpus", "2", "--workload", "stub"], {"HM_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0 and "rank 1 failed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
