@@ -23,6 +23,7 @@
 #include <string>
 
 #include "../../include/hivemind_amd.h"
+#include "hm_queue.hpp"
 
 int hm_fail(int code, const std::string& msg);
 
@@ -620,18 +621,14 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
     }
 }
 
-template <int CTILES, bool K5>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
-__global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
-                                                              const h16* __restrict__ planes, int n, int copMax, int uHalfs,
-                                                              h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
-                                                              h16* __restrict__ wdl, h16* __restrict__ ml,
-                                                              const int* __restrict__ groupRows, int group,
-                                                              unsigned long long* __restrict__ dbg, unsigned long long* __restrict__ clk) {
-    if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // leg clock: (start, end) pair
-    int dbgN = 0;
+// One position through the whole network by one workgroup of 8 waves (the body of rise_forward_narrow and of the persistent
+// evaluator rise_serve): input row `pin`, outputs to row `sIdx` of the head tensors.
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const NetDesc& nd = *ndp;
+template <int CTILES, bool K5>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
+__device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __restrict__ wh, const float* __restrict__ wf, const h16* pin, size_t sIdx,
+                                                int copMax, int uHalfs, unsigned char* smem,
+                                                h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB, h16* __restrict__ wdl, h16* __restrict__ ml,
+                                                unsigned long long* __restrict__ dbg, int& dbgN) {
     // C = 64, 128 or 384: an N = C GEMM is CTILES column tiles x 2 square tiles = 2*CTILES tiles of 32x32 over 8 waves, i.e.
     // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
     // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
@@ -650,15 +647,13 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
     const int stile = wave & 1;                                         // the square half of every tile this wave computes
     const int sqL = stile * 32 + (lane & 31);                           // the square this lane feeds as an A-row / B-column
 
-    for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
-        if (groupRows && (sIdx % group) >= groupRows[sIdx / group]) continue;
+    {
         HM_STAMP();
         // ---- input planes: NCHW [74][64] fp16 -> Ss as [sq][cin_pad] (+ zero row 64)
         const int ldi = nd.cin_pad + 8;
         for (int i = tid; i < 65 * ldi; i += 512) Ss[i] = (h16)0.0f;
         for (int i = tid; i < ldx; i += 512) Xs[64 * ldx + i] = (h16)0.0f;
         __syncthreads();
-        const h16* pin = planes + (size_t)sIdx * HM_PLANE_VALUES;
         for (int i = tid; i < HM_PLANE_VALUES; i += 512) Ss[(i & 63) * ldi + (i >> 6)] = pin[i];
         __syncthreads();
         HM_STAMP();   // input staged
@@ -897,9 +892,69 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
         __syncthreads();
         HM_STAMP();
     }
-    if (clk && threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#undef HM_STAMP
 }
+
+template <int CTILES, bool K5>
+__global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
+                                                              const h16* __restrict__ planes, int n, int copMax, int uHalfs,
+                                                              h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB,
+                                                              h16* __restrict__ wdl, h16* __restrict__ ml,
+                                                              const int* __restrict__ groupRows, int group,
+                                                              unsigned long long* __restrict__ dbg, unsigned long long* __restrict__ clk) {
+    if (clk && threadIdx.x == 0) atomicMin(clk, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // leg clock: (start, end) pair
+    int dbgN = 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const NetDesc& nd = *ndp;
+    for (int sIdx = blockIdx.x; sIdx < n; sIdx += gridDim.x) {
+        if (groupRows && (sIdx % group) >= groupRows[sIdx / group]) continue;
+        narrow_position<CTILES, K5>(nd, wh, wf, planes + (size_t)sIdx * HM_PLANE_VALUES, (size_t)sIdx, copMax, uHalfs, smem, value, piA, piB, wdl, ml, dbg, dbgN);
+    }
+    if (clk && threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// Persistent evaluator (hm_queue.hpp): every workgroup takes one position at a time from the device-side queue the search
+// workgroups fill, runs the whole network on it and signals the owning game, until the queue hands it IT_POISON.  Replaces
+// the per-iteration forward launch of the lockstep loop: a batch is evaluated as soon as its game has written it, eight
+// positions of one game by eight workgroups at once.
+template <int CTILES, bool K5>
+__global__ __launch_bounds__(512, 1) void rise_serve(const NetDesc* __restrict__ ndp, const h16* __restrict__ wh, const float* __restrict__ wf,
+                                                     int copMax, int uHalfs, hmq::ServeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned s_item;
+    const NetDesc& nd = *ndp;
+    int dbgN = 0;
+    unsigned long long ticks = 0, count = 0;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.q->consIn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const unsigned it = hmq::pop_item(a.q);
+            if (it != hmq::IT_POISON) hmq::acquire_agent();         // the game's plane row: one invalidate, then plain loads
+            s_item = it;
+        }
+        __syncthreads();
+        const unsigned it = s_item;
+        if (it == hmq::IT_POISON) break;                            // uniform
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const int g = hmq::item_game(it), buf = hmq::item_buf(it), row = hmq::item_row(it);
+        const size_t r = (size_t)g * 8 + row;
+        narrow_position<CTILES, K5>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
+                                    reinterpret_cast<h16*>(a.value[buf]), reinterpret_cast<h16*>(a.piA[buf]), reinterpret_cast<h16*>(a.piB[buf]),
+                                    reinterpret_cast<h16*>(a.wdl[buf]), reinterpret_cast<h16*>(a.ml[buf]), nullptr, dbgN);
+        hmq::drain_stores();                                        // every wave stored part of the heads
+        __syncthreads();                                            // (also: every thread has read s_item)
+        if (threadIdx.x == 0) {
+            hmq::release_agent();
+            __hip_atomic_fetch_add(&a.done[g * 2 + buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticks += __builtin_amdgcn_s_memrealtime() - t0; ++count;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (a.clkSum && count) { atomicAdd(a.clkSum, ticks); atomicAdd(a.clkCnt, count); }
+        __hip_atomic_fetch_add(&a.q->served, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&a.q->consOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#undef HM_STAMP
 
 }  // namespace hmn
 
@@ -947,6 +1002,24 @@ static hipError_t with_narrow(const hm_net* net, F f) {
     if (net->nd.C == 384) return net->k5 ? f(rise_forward_narrow<12, true>) : f(rise_forward_narrow<12, false>);
     return net->k5 ? f(rise_forward_narrow<4, true>) : f(rise_forward_narrow<4, false>);
 }
+int hm_net_can_serve(const hm_net* net) { return net && net->narrow ? 1 : 0; }
+int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t st) {
+    using namespace hmn;
+    if (!net || !net->narrow || grid <= 0) return hm_fail(HM_ERR_INVALID, "hm_net_serve: this network has no persistent evaluator kernel");
+    auto launch = [&](auto kern) {
+        static_cast<void>(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->ldsNarrow));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), net->ldsNarrow, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),
+                           net->copMax, net->uHalfs, args);
+        return hipGetLastError();
+    };
+    hipError_t e;
+    if (net->nd.C == 64) e = net->k5 ? launch(rise_serve<2, true>) : launch(rise_serve<2, false>);
+    else if (net->nd.C == 384) e = net->k5 ? launch(rise_serve<12, true>) : launch(rise_serve<12, false>);
+    else e = net->k5 ? launch(rise_serve<4, true>) : launch(rise_serve<4, false>);
+    if (e != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("rise_serve launch failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
 template <typename F>
 static hipError_t with_kernel(const hm_net* net, bool wide, F f) {
     using namespace hmn;

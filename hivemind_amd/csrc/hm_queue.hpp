@@ -1,0 +1,132 @@
+// hm_queue.hpp — device-side evaluation queue between the persistent search kernel (k_search, hm_search.hip: one workgroup per
+// game, alive for a whole search) and the persistent evaluator kernel (rise_serve, hm_net.hip: one workgroup per position at a
+// time), replacing the host-driven lockstep of Engine::enqueueInferenceHalf / synchronizeInferenceHalf (nn/engine.h:43-81) inside
+// SearchThread::run_iteration (searchthread.cc:661-739) for the native evaluator.
+//
+// Why: in the lockstep form every iteration of every game waits for the slowest game's collect and for one forward launch over all
+// games; with the queue a game's chain collect(k+1) -> [eval(k) done?] -> process(k) advances at its own pace and the evaluator
+// starts on a batch the moment its game has written it.  The order of tree operations per game — hence every result — is unchanged.
+//
+// Protocol (MI355X: 8 XCDs with private L2s, per-CU L1 never refreshed by other CUs' stores; cdna_hip_programming.md Guideline 16):
+//   producer of bulk data (plane rows + move lists, or the network heads): plain stores; EVERY storing wave drains (s_waitcnt
+//   vmcnt(0)); workgroup barrier; ONE lane: agent-scope release fence, drain again (the compiler may drop the fence's own wait),
+//   then the signal — an 8-byte {ticket tag, payload} granule stored with a relaxed agent-scope atomic (queue slot), or an
+//   agent-scope atomic add (completion counter);
+//   consumer: ONE lane polls the ONE word relaxed (s_sleep between polls), then ONE agent-scope acquire fence + drain, workgroup
+//   barrier, then plain loads by every wave.
+//   Every polled word is zeroed by a hipMemsetAsync ahead of the launches; tags / counters count within one search.
+//   Every spin is bounded: on give-up the spinner sets SrvQueue::error and leaves, and every other spinner sees that word.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace hmq {
+
+typedef unsigned long long u64q;
+constexpr int QCAP = 8192;                   // ring slots (power of two) >> rows in flight (16 per game) + idle consumers
+constexpr u64q SPIN_LIMIT_TICKS = 2000000000ULL;   // 20 s of the 100 MHz s_memrealtime counter: a hang guard, not a schedule
+constexpr u64q MEET_LIMIT_TICKS = 300000000ULL;    // 3 s: by then the other kernel of the pair must have started (error 4: not concurrent)
+
+// item payload (low 32 bits of a slot): game slot, plane buffer, row, evaluator-specific flags
+constexpr unsigned IT_POISON = 0x80000000u;  // no more work: the consumer leaves
+__host__ __device__ inline unsigned item_pack(int game, int buf, int row, int net) { return (unsigned)game | ((unsigned)buf << 20) | ((unsigned)row << 21) | ((unsigned)net << 24); }
+__host__ __device__ inline int item_game(unsigned it) { return (int)(it & 0xfffffu); }
+__host__ __device__ inline int item_buf(unsigned it) { return (int)((it >> 20) & 1u); }
+__host__ __device__ inline int item_row(unsigned it) { return (int)((it >> 21) & 7u); }
+__host__ __device__ inline int item_net(unsigned it) { return (int)((it >> 24) & 1u); }
+
+struct SrvQueue {                            // one per search engine; zeroed (whole struct) before every search
+    unsigned head;                           // next ticket a consumer takes
+    unsigned tail;                           // next ticket a producer fills
+    unsigned producers;                      // search workgroups still running (set by the host after the memset)
+    unsigned error;                          // != 0: some spin gave up (code of the first), everybody leaves
+    unsigned consumers;                      // evaluator workgroups of this launch (poison count)
+    unsigned served;                         // items evaluated (statistics)
+    unsigned treesIn, treesOut, consIn, consOut;   // census of both kernels (diagnostics of a give-up)
+    unsigned dbg[6];                         // first failed wait of a search workgroup: game, buffer, rows expected, rows done, iteration, ms since the kernel's first workgroup started
+    u64q slots[QCAP];                        // {ticket + 1, payload}
+};
+static_assert(sizeof(SrvQueue) % 16 == 0, "zeroed as one block of 16-byte multiples");
+
+#define HMQ_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ONE lane, after every storing wave has drained and the workgroup has met at a barrier
+__device__ __forceinline__ void release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// ONE lane, after its relaxed poll has matched; the workgroup barrier that follows holds the other waves until the invalidate is done
+__device__ __forceinline__ void acquire_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ bool spin_expired(u64q t0) { return (u64q)__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS; }
+
+// producer, ONE lane (release done): n items with consecutive tickets
+__device__ __forceinline__ void push_items(SrvQueue* q, const unsigned* items, int n) {
+    const unsigned t = __hip_atomic_fetch_add(&q->tail, (unsigned)n, HMQ_RLX);
+    for (int i = 0; i < n; ++i)
+        __hip_atomic_store(&q->slots[(t + i) & (QCAP - 1)], ((u64q)(t + i + 1) << 32) | items[i], HMQ_RLX);
+}
+// the last producer to leave releases every consumer (ONE lane)
+__device__ __forceinline__ void producer_exit(SrvQueue* q) {
+    if (__hip_atomic_fetch_sub(&q->producers, 1u, HMQ_RLX) != 1u) return;
+    const unsigned n = __hip_atomic_load(&q->consumers, HMQ_RLX);
+    const unsigned t = __hip_atomic_fetch_add(&q->tail, n, HMQ_RLX);
+    for (unsigned i = 0; i < n; ++i)
+        __hip_atomic_store(&q->slots[(t + i) & (QCAP - 1)], ((u64q)(t + i + 1) << 32) | IT_POISON, HMQ_RLX);
+}
+// consumer, ONE lane: next item (blocks; IT_POISON on shutdown, error or give-up).  No acquire yet.
+__device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
+    const unsigned t = __hip_atomic_fetch_add(&q->head, 1u, HMQ_RLX);
+    u64q* slot = &q->slots[t & (QCAP - 1)];
+    const u64q t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 0;; ++spins) {
+        const u64q v = __hip_atomic_load(slot, HMQ_RLX);
+        if ((unsigned)(v >> 32) == t + 1) return (unsigned)v;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(&q->error, HMQ_RLX)) return IT_POISON;
+            const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
+            // no search workgroup has started while this one has been waiting: the two kernels are being run one after the other
+            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(&q->treesIn, HMQ_RLX) == 0u) { __hip_atomic_store(&q->error, 4u, HMQ_RLX); return IT_POISON; }
+            if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(&q->error, 2u, HMQ_RLX); return IT_POISON; }
+        }
+    }
+}
+// waiter, ONE lane: until *counter >= want (false: error / give-up).  No acquire yet.
+__device__ __forceinline__ bool wait_count(SrvQueue* q, unsigned* counter, unsigned want) {
+    const u64q t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(counter, HMQ_RLX) >= want) return true;
+        __builtin_amdgcn_s_sleep(4);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(&q->error, HMQ_RLX)) return false;
+            if (spin_expired(t0)) { __hip_atomic_store(&q->error, 3u, HMQ_RLX); return false; }
+        }
+    }
+}
+
+// what the persistent evaluator kernel needs besides the network: both plane buffers, both sets of heads, the queue, the
+// per-(game, buffer) completion counters and optional accumulators of the per-position time
+struct ServeArgs {
+    const uint16_t* planes[2];
+    uint16_t* value[2];
+    uint16_t* piA[2];
+    uint16_t* piB[2];
+    uint16_t* wdl[2];
+    uint16_t* ml[2];
+    SrvQueue* q;
+    unsigned* done;
+    u64q* clkSum;                            // += ticks (100 MHz) spent evaluating, or nullptr
+    u64q* clkCnt;                            // += positions evaluated
+};
+
+}  // namespace hmq
+
+struct hm_net;
+// hm_net.hip: 1 when `net` has a persistent evaluator kernel (the 8-wave narrow trunks: C = 64, 128, 384)
+int hm_net_can_serve(const hm_net* net);
+// hm_net.hip: launches `grid` persistent evaluator workgroups on `stream`; they leave when the queue hands them IT_POISON
+int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t stream);

@@ -44,6 +44,7 @@ __device__ int g_traceGame = -1;
 #include "hm_prof.hpp"
 #include "hm_rules_device.hpp"
 #include "hm_host.hpp"
+#include "hm_queue.hpp"
 
 using namespace hmd;
 
@@ -150,7 +151,10 @@ struct Params {          // device-visible configuration + pool geometry
 // kernel min-/max-es its start / end into the leg's interval, the next kernel in stream order folds the finished interval into a
 // running sum.  Gives the exact average launch duration of k_collect / the forward / k_process over ALL launches (graph-replayed
 // ones included), the figure a rocprofv3 kernel trace reports.
-struct LegClock { u64 cStart, cEnd, nStart, nEnd, pStart, pEnd; u64 sumC, sumN, sumP; u64 cntC, cntN, cntP; };
+struct LegClock { u64 cStart, cEnd, nStart, nEnd, pStart, pEnd; u64 sumC, sumN, sumP; u64 cntC, cntN, cntP; u64 sumW; };
+// Persistent search (k_search / rise_serve): no launches to bracket, so the same sums count per game-iteration — sumC / sumP the
+// ticks a game spent in its collect / process phases (cntC = cntP = game-iterations), sumW the ticks it waited for the evaluation
+// of its pending batch, sumN / cntN the evaluator's ticks and positions.
 
 struct Pools {
     LegClock* clk;
@@ -1529,6 +1533,78 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
     if (lane == 0) { pl.leafCounts[base + b] = kept; atomicAdd(&L.listWords, kept); }
 }
 
+// The three helper waves of a game's collect phase (k_collect and the persistent k_search): classifier (wave 1), plane writer
+// (wave 2), generator (wave 3).  Each returns once the traversal wave has raised svcStop and every request has been served.
+__device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, WaveLds& L, const Pools& pl, const Game& s_game, int g, uint16_t* planesNext, int wave) {
+    if (wave == 1) {
+        // classifier: serves the traversal's leaf requests in order; ends once the traversal has stopped and every request is served
+        const int rootTeam = s_game.team;
+        const bool rootAdv = s_game.adv != 0;
+        int seen = 0;
+        for (;;) {
+            int rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rs == seen) {
+                if (!__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(1); continue; }
+                rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rs == seen) break;
+            }
+            seen++;                                                // requests are served one by one, in order
+            serve_leaf(s, s_rt, L, rootTeam, rootAdv, seen);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (wave == 3) {
+        // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328) and, between
+        // them, the board-B legal move list of every posted leaf image (the plane-writer wave does the planes and board A)
+        int seen = 0, servedB = 0;
+        for (;;) {
+            const int rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (rs != seen) {
+                const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
+                GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
+                GenHdr h = *gh;
+                gen_push(s, h, iA + 1, iB);
+                gen_push(s, h, iA, iB + 1);
+                *gh = h;
+                if ((threadIdx.x & 63) == 0) s.nodes[node].more = h.heapSize > 0;
+                wave_fence();
+                seen = rs;
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+            const int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (servedB < posted) {
+                const int img = servedB & (BATCH - 1);
+                leaf_move_list(pl, s_rt, L, g, img, L.postRow[img], 1);
+                servedB++;
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+            // nothing to do: leave once the traversal has stopped (no more refills) and the classifier is done (no more images)
+            if (__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) && __hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+                && __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen
+                && __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == servedB) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    } else {
+        uint16_t* dst = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
+        int served = 0;
+        for (;;) {                                                 // ends once the classifier has set `done` and every post is served
+            int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (served >= posted) {
+                if (!__hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(4); continue; }
+                posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (served >= posted) break;
+            }
+            const int img = served & (BATCH - 1), row = L.postRow[img];
+            write_planes_f16(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
+            leaf_move_list(pl, s_rt, L, g, img, row, 0);
+            served++;
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // Two waves per game: wave 0 walks the tree; wave 1 (another SIMD of the same CU) turns the hm_board images wave 0
 // posts in LDS into fp16 planes, so the 9.4 KB plane writes overlap the next descent instead of extending it.
 //
@@ -1606,73 +1682,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[30] += __builtin_amdgcn_s_memtime() - ta; s_prof[31] += __builtin_amdgcn_s_memrealtime() - rt0_; }
         if (threadIdx.x == 0 && blockIdx.x < 64 && searching && g_colLaunch < PROF_LAUNCHES) g_colDur[g_colLaunch][blockIdx.x] = (unsigned int)(__builtin_amdgcn_s_memtime() - ta);
 #endif
-    } else if (wave == 1) {
-        // classifier: serves the traversal's leaf requests in order; ends once the traversal has stopped and every request is served
-        const int rootTeam = s_game.team;
-        const bool rootAdv = s_game.adv != 0;
-        int seen = 0;
-        for (;;) {
-            int rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (rs == seen) {
-                if (!__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(1); continue; }
-                rs = __hip_atomic_load(&L.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (rs == seen) break;
-            }
-            seen++;                                                // requests are served one by one, in order
-            serve_leaf(s, s_rt, L, rootTeam, rootAdv, seen);
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else if (wave == 3) {
-        // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328) and, between
-        // them, the board-B legal move list of every posted leaf image (the plane-writer wave does the planes and board A)
-        int seen = 0, servedB = 0;
-        for (;;) {
-            const int rs = __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (rs != seen) {
-                const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
-                GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
-                GenHdr h = *gh;
-                gen_push(s, h, iA + 1, iB);
-                gen_push(s, h, iA, iB + 1);
-                *gh = h;
-                if ((threadIdx.x & 63) == 0) s.nodes[node].more = h.heapSize > 0;
-                wave_fence();
-                seen = rs;
-                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-            const int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (servedB < posted) {
-                const int img = servedB & (BATCH - 1);
-                leaf_move_list(pl, s_rt, L, blockIdx.x, img, L.postRow[img], 1);
-                servedB++;
-                if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-            // nothing to do: leave once the traversal has stopped (no more refills) and the classifier is done (no more images)
-            if (__hip_atomic_load(&L.svcStop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) && __hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
-                && __hip_atomic_load(&L.gq.reqSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == seen
-                && __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == servedB) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    } else {
-        uint16_t* dst = planesNext + (size_t)blockIdx.x * BATCH * HM_PLANE_VALUES;
-        int served = 0;
-        for (;;) {                                                 // ends once the classifier has set `done` and every post is served
-            int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (served >= posted) {
-                if (!__hip_atomic_load(&L.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { __builtin_amdgcn_s_sleep(4); continue; }
-                posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (served >= posted) break;
-            }
-            const int img = served & (BATCH - 1), row = L.postRow[img];
-            write_planes_f16(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
-            leaf_move_list(pl, s_rt, L, blockIdx.x, img, row, 0);
-            served++;
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
+    } else collect_helper_role(s, s_rt, L, pl, s_game, blockIdx.x, planesNext, wave);
     PROF_T(tdr);
     __syncthreads();
     PROF_ADD(25, tdr);
@@ -1719,6 +1729,211 @@ __global__ __launch_bounds__(64 * (BATCH + 1)) void k_process(Pools pl, Params p
     if (blockIdx.x == 0 && threadIdx.x == 0) g_colLaunch++;
 #endif
     PROF_FLUSH();
+}
+
+// =======================================================================================
+// Persistent search: ONE launch per search instead of ~50 lockstep iterations of three kernels.
+// =======================================================================================
+// k_search keeps a game's workgroup alive for the whole node-budget search (Agent::run_search worker loop, agent.cc:331-352 +
+// SearchThread::run_iteration, searchthread.cc:661-739): the node pool and the Game record stay in LDS from the first descent to
+// the last backup, and the evaluator is another persistent kernel (rise_serve, hm_net.hip) fed through a device-side queue
+// (hm_queue.hpp).  Per game the sequence of tree operations is exactly the lockstep one — collect b0, collect b1, process b0,
+// collect b2, process b1, ... with the finish / abort rules of finish_pending / discard_pending_iteration — so every result is
+// bit-identical; what changes is who waits for whom: a game waits only for the evaluation of ITS pending batch, never for the
+// slowest game of the launch, and the evaluator starts on a batch as soon as its game has written it.
+// Waves: 0 traversal + ordered backups, 1 classifier, 2 plane writer, 3 generator during a collect phase; during a process
+// phase waves 1..3 expand the batch's leaves (leaf i on wave 1 + i % 3) beside wave 0's backups.
+struct SearchIo {
+    uint16_t* planes[2];                     // [nGames * BATCH][74][64] fp16 per buffer
+    NetOut out[2];                           // heads of buffer 0 / 1 (rows g * BATCH + slot)
+    hmq::SrvQueue* q;
+    unsigned* done;                          // [nGames][2] rows evaluated per (game, buffer), cumulative over the search
+    const uint8_t* netSel;                   // per game: evaluator index of its items (nullptr: 0)
+    int ldsNodes;                            // the node pool fits in LDS beside k_search's static LDS
+};
+struct SearchCtl { int action, buf, first, ok; };
+enum : int { ACT_COLLECT = 0, ACT_FINISH = 1 };
+
+__device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L, int wave, int pending, int nctx, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+    for (int i = wave - 1; i < nctx; i += 3) expand_context(s, rt, L, pending, i, rootTeam, rootAdv, out, rowBase);
+}
+
+__global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm, SearchIo io) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    __shared__ ExpLds s_exp2[2];                                    // expansion scratch of waves 2 and 3 (wave 1 uses L.exp)
+    __shared__ __attribute__((aligned(16))) Game s_game;
+    constexpr int TABN = 512;
+    __shared__ float s_cpuct[TABN];
+    __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
+    __shared__ SearchCtl s_ctl;
+    __shared__ unsigned s_expect[2];                                // rows published per buffer so far
+    const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    G s = make_view(pl, prm, g);
+    Game* const gGame = s.g;
+    Node* const gNodes = s.nodes;
+    for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
+    stage_table_wide(&s_rt, pl.rules);
+    {
+        const bool alt = gGame->pwSel != 0;
+        const int* pwr = alt ? pl.pwRootAlt : pl.pwRoot;
+        const int* pwn = alt ? pl.pwNodeAlt : pl.pwNode;
+        for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
+    }
+    if (threadIdx.x == 0) { s_expect[0] = s_expect[1] = 0; s_ctl.action = ACT_COLLECT; s_ctl.buf = 0; s_ctl.first = 1; s_ctl.ok = 1; L.listWords = 0; }
+    __syncthreads();
+    const bool searching = s_game.status == ST_SEARCHING;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&io.q->treesIn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!searching) {                                               // idle slot, or a search k_begin already settled
+        if (threadIdx.x == 0) { __hip_atomic_fetch_add(&io.q->treesOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hmq::producer_exit(io.q); }
+        return;
+    }
+    const bool mirror = io.ldsNodes != 0;
+    if (mirror) {
+        const int words = s_game.nodeCount * 4;
+        const uint4* src = reinterpret_cast<const uint4*>(gNodes);
+        uint4* dst = reinterpret_cast<uint4*>(s_nodes);
+        for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
+        s.nodes = reinterpret_cast<Node*>(s_nodes);
+        __syncthreads();
+    }
+    s.g = &s_game;
+    s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
+    if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
+    const int rootTeam = s_game.team;
+    const bool rootAdv = s_game.adv != 0;
+    const int rowBase = g * BATCH;
+    ExpLds& myExp = wave <= 1 ? L.exp : s_exp2[wave - 2];
+    u64 tC = 0, tW = 0, tP = 0, nIt = 0;                            // thread 0: ticks spent collecting / waiting for the evaluator / processing
+    // process of the pending batch: wait for its evaluation (unless `abortIt`), backups on wave 0 beside the expansions on waves 1..3
+    auto process_pending = [&](bool abortIt) -> bool {
+        const int pending = s_game.pending;
+        u64 t0 = 0;
+        if (threadIdx.x == 0) {
+            t0 = __builtin_amdgcn_s_memrealtime();
+            bool ok = true;
+            if (!abortIt && s_game.validCount[pending] > 0) {
+                ok = hmq::wait_count(io.q, &io.done[g * 2 + pending], s_expect[pending]);
+                if (ok) hmq::acquire_agent();
+                else if (atomicCAS(&io.q->dbg[0], 0u, (unsigned)g + 1u) == 0u) {
+                    io.q->dbg[1] = (unsigned)pending; io.q->dbg[2] = s_expect[pending];
+                    io.q->dbg[3] = __hip_atomic_load(&io.done[g * 2 + pending], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    io.q->dbg[4] = (unsigned)nIt; io.q->dbg[5] = (unsigned)(((u64)__builtin_amdgcn_s_memrealtime() - t0) / 100000ULL);
+                }
+            }
+            s_ctl.ok = ok ? 1 : 0;
+            const u64 t1 = __builtin_amdgcn_s_memrealtime();
+            tW += t1 - t0; t0 = t1;
+        }
+        __syncthreads();
+        if (!s_ctl.ok) return false;
+        const int nctx = s_game.ctxCount[pending];
+        __syncthreads();                                            // every wave holds the batch header before wave 0 retires it
+        if (wave == 0) {
+            if (abortIt) abort_batch(s, pending);                   // discard_pending_iteration (agent.cc:343-352)
+            else backup_batch(s, pending, &io.out[pending], rowBase);
+        } else if (!abortIt) expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase);
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) tP += __builtin_amdgcn_s_memrealtime() - t0;
+        return true;
+    };
+    for (;;) {
+        // ---- control: worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
+        if (threadIdx.x == 0) {
+            const bool fin = s_game.nodesSearched >= s_game.targetNodes || s.nodes[s_game.root].type != T_UNSOLVED || s_game.overflow;
+            const bool first = s_game.pending < 0;
+            s_ctl.action = fin ? ACT_FINISH : ACT_COLLECT;
+            s_ctl.first = first ? 1 : 0;
+            s_ctl.buf = first ? 0 : 1 - s_game.pending;
+            // hand-off state of one collect phase
+            L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0;
+            L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
+        }
+        __syncthreads();
+        if (s_ctl.action == ACT_FINISH) {
+            // finish_pending / discard_pending_iteration (agent.cc:343-352)
+            bool ok = true;
+            if (s_game.pending >= 0) {
+                const bool solvedOrOverflow = s.nodes[s_game.root].type != T_UNSOLVED || s_game.overflow;
+                ok = process_pending(solvedOrOverflow);
+            }
+            if (threadIdx.x == 0) {
+                s_game.pending = -1;
+                if (!ok) s_game.overflow |= 128;
+                s_game.status = s_game.overflow ? ST_ERROR : ST_DONE;
+            }
+            break;
+        }
+        const int buf = s_ctl.buf;
+        const bool first = s_ctl.first != 0;
+        u64 t0 = 0;
+        if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+        // ---- collect phase (collect_batch, searchthread.cc:255-442) into plane buffer `buf`
+        if (wave == 0) {
+            s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0;
+            collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
+            if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else collect_helper_role(s, s_rt, L, pl, s_game, g, io.planes[buf], wave);
+        hmq::drain_stores();                                        // plane rows and move lists of this batch have left every wave
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int valid = s_game.validCount[buf];
+            if (valid > 0) {                                        // hand the batch to the evaluator
+                hmq::release_agent();
+                unsigned items[BATCH];
+                const int net = io.netSel ? io.netSel[g] : 0;
+                for (int r = 0; r < valid; ++r) items[r] = hmq::item_pack(g, buf, r, net);
+                s_expect[buf] += (unsigned)valid;
+                hmq::push_items(io.q, items, valid);
+            }
+            const u64 t1 = __builtin_amdgcn_s_memrealtime();
+            tC += t1 - t0; nIt++;
+        }
+        if (first) {
+            // with nothing in flight the first batch went to buffer 0 and its lookahead follows
+            if (wave == 0) {
+                if (s_game.ctxCount[0] == 0) { if (lane == 0) s_game.overflow |= 16; }                      // no progress possible
+                else if (s_game.validCount[0] == 0) process_batch(s, s_rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0);
+                else if (lane == 0) s_game.pending = 0;
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---- process of the batch whose evaluation was requested one collect ago (process_batch, searchthread.cc:444-639)
+        if (!process_pending(false)) {
+            if (threadIdx.x == 0) { s_game.overflow |= 128; s_game.pending = -1; s_game.status = ST_ERROR; }
+            break;
+        }
+        if (wave == 0) {                                            // run_iteration tail
+            const int look = 1 - s_game.pending;
+            if (lane == 0) s_game.pending = -1;
+            wave_fence();
+            if (s_game.validCount[look] == 0) process_batch(s, s_rt, L.exp, look, rootTeam, rootAdv, nullptr, 0);
+            else if (lane == 0) s_game.pending = look;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- write the tree and the game record back; the last search workgroup to leave releases the evaluator
+    if (threadIdx.x == 0) { s_game.listWords += L.listWords; s_game.nodesVisited += s.nv; s_game.edgesScanned += s.es; }
+    __syncthreads();
+    if (mirror) {
+        const int words = s_game.nodeCount * 4;
+        const uint4* src = reinterpret_cast<const uint4*>(s_nodes);
+        uint4* dst = reinterpret_cast<uint4*>(gNodes);
+        for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
+    if (threadIdx.x == 0) {
+        LegClock* ck = pl.clk;                                      // per game-iteration sums (100 MHz ticks)
+        atomicAdd(&ck->sumC, tC); atomicAdd(&ck->sumW, tW); atomicAdd(&ck->sumP, tP);
+        atomicAdd(&ck->cntC, nIt); atomicAdd(&ck->cntP, nIt);
+        __hip_atomic_fetch_add(&io.q->treesOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hmq::producer_exit(io.q);
+    }
 }
 
 // Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
@@ -2351,6 +2566,16 @@ struct hm_sp {
     float pwExponent = 0.4f, altPw = -1.0f, altRootPw = -1.0f;
     int *d_pwRootAlt = nullptr, *d_pwNodeAlt = nullptr;
     size_t ldsMirrorMax = 0;               // LDS left beside k_collect's static LDS (the largest node mirror a CU admits)
+    // persistent search (hm_sp_search): [SrvQueue | done counters of every (game, buffer)] — one block, zeroed before every search
+    unsigned char* d_queue = nullptr;
+    size_t queueBytes = 0;
+    int searchLdsNodes = 0;                // the node pool fits beside k_search's static LDS
+    int numCUs = 0;
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evT0 = nullptr, evT1 = nullptr;
+    hipStream_t sTree = nullptr, sNet = nullptr;   // queues of their own for the two persistent kernels
+    unsigned lastQueueError = 0;           // SrvQueue::error of the last hm_sp_search (4: the two kernels did not run together)
+    bool lastBeginMasked = false;          // hm_sp_begin_search was given a mask (hm_sp_begin_again relaunches with the same inputs)
+    unsigned* h_qinit = nullptr;           // pinned: {producers, error, consumers} as uploaded after the memset
     // Per-ply traffic with the host goes through two pinned staging blocks and contiguous device blocks: one copy per call
     // and direction instead of one per array (a pageable hipMemcpy costs tens of microseconds before the first byte moves).
     unsigned char* h_stage = nullptr;      // pinned
@@ -2531,6 +2756,24 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
         if (hipHostMalloc(reinterpret_cast<void**>(&sp->h_stage), sp->stageBytes, hipHostMallocDefault) != hipSuccess) { hm_sp_destroy(sp); return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed"); }
     }
     rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 2) /* [0] active games */;
+    {
+        sp->queueBytes = sizeof(hmq::SrvQueue) + ((G_ * 2 * sizeof(unsigned) + 15) & ~(size_t)15);
+        rc |= dalloc(sp, &sp->d_queue, sp->queueBytes);
+        hipFuncAttributes fa;
+        size_t staticLds = 64 * 1024;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_search)) == hipSuccess) staticLds = fa.sharedSizeBytes;
+        else (void)hipGetLastError();
+        const size_t room = staticLds < 160 * 1024 ? 160 * 1024 - staticLds : 0;
+        sp->searchLdsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+        if (sp->searchLdsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) != hipSuccess) {
+            (void)hipGetLastError();
+            sp->searchLdsNodes = 0;
+        }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) sp->numCUs = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+    }
     rc |= dalloc(sp, &sp->d_term, G_);
     rc |= dalloc(sp, &sp->raw.moves, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.probs, G_ * 2 * HM_MAX_MOVES);
     rc |= dalloc(sp, &sp->raw.caps, G_ * 2 * HM_MAX_MOVES); rc |= dalloc(sp, &sp->raw.counts, G_ * 2); rc |= dalloc(sp, &sp->raw.onTurn, G_ * 2);
@@ -2586,12 +2829,27 @@ int hm_sp_leg_times(hm_sp* sp, double* ms3, uint64_t* counts3, int reset) {
     }
     return 0;
 }
+// persistent searches: total time (ms) the games waited for the evaluation of their pending batches since the last reset
+int hm_sp_wait_time(hm_sp* sp, double* ms) {
+    if (!sp || !ms) return hm_fail(HM_ERR_INVALID, "null argument");
+    LegClock c;
+    HIPCHK(hipMemcpy(&c, sp->pl.clk, sizeof c, hipMemcpyDeviceToHost));
+    *ms = (double)c.sumW * 1e-5;
+    return 0;
+}
 // device pointer to the forward's (start, end) pair of the leg clock
 uint64_t* hm_sp_leg_clock_net(hm_sp* sp) { return sp ? reinterpret_cast<uint64_t*>(&sp->pl.clk->nStart) : nullptr; }
 
 int hm_sp_destroy(hm_sp* sp) {
     if (!sp) return 0;
     if (sp->h_stage) (void)hipHostFree(sp->h_stage);
+    if (sp->h_qinit) (void)hipHostFree(sp->h_qinit);
+    if (sp->evFork) (void)hipEventDestroy(sp->evFork);
+    if (sp->evJoin) (void)hipEventDestroy(sp->evJoin);
+    if (sp->evT0) (void)hipEventDestroy(sp->evT0);
+    if (sp->evT1) (void)hipEventDestroy(sp->evT1);
+    if (sp->sTree) (void)hipStreamDestroy(sp->sTree);
+    if (sp->sNet) (void)hipStreamDestroy(sp->sNet);
     for (void* p : sp->allocs) (void)hipFree(p);
     delete sp;
     return 0;
@@ -2647,8 +2905,22 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
         HIPCHK(hipMemcpy(sp->pl.noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     sp->alpha = alpha; sp->eps = eps;
+    sp->lastBeginMasked = mask != nullptr;
     return 0;
 }
+// The prologue of the last hm_sp_begin_search once more, from the inputs still on the device (targets, seeds, mask, noise draws):
+// puts every slot back to the start of its search after a persistent search that could not run (hm_sp_search_not_concurrent).
+// Only valid with tree reuse off and before any other hm_sp_* call that uploads moves or masks.
+int hm_sp_begin_again(hm_sp* sp) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    hipLaunchKernelGGL(k_begin, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, sp->alpha, sp->eps, sp->lastBeginMasked ? sp->d_mask : nullptr, sp->d_rootHash);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+// 1 when the last hm_sp_search failed because its two kernels were run one after the other (a serialising profiler, or a
+// runtime that put both streams on one hardware queue): the lockstep calls still work.
+int hm_sp_search_not_concurrent(const hm_sp* sp) { return sp && sp->lastQueueError == 4u ? 1 : 0; }
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
@@ -2670,6 +2942,109 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
         HIPCHK(hipMemcpyAsync(active_games, sp->d_active, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+// Evaluator workgroups a persistent search of this engine can run beside its game workgroups: every workgroup of either kind may
+// need a whole CU (the search kernel takes the full register file, the evaluator most of the LDS), so all of them are resident —
+// which the queue protocol relies on only for speed, the spins being bounded — when their number does not exceed the CU count.
+int hm_sp_search_consumers(const hm_sp* sp) {
+    if (!sp || sp->numCUs <= 0) return 0;
+    // Workgroups are dealt round-robin over the XCDs and, inside an XCD, over its shader engines, IN ORDER: a workgroup whose
+    // engine has no free CU waits there — and holds up every workgroup behind it — even while other engines have room (observed:
+    // with one CU per XCD left free, a game workgroup waited until the evaluator kernel gave up).  So the evaluator takes the same
+    // number of CUs in every shader engine (8 XCDs x 4 engines of 8 CUs on MI355X) and leaves each engine room for its share of the
+    // game workgroups plus one.
+    const int engines = 32, perEngine = sp->numCUs / engines;
+    if (perEngine < 2) return 0;
+    const int gamesPerXcd = (sp->nGames + 7) / 8, gamesPerEngine = (gamesPerXcd + 3) / 4;
+    const int n = (perEngine - gamesPerEngine - 1) * engines;
+    return n >= 8 ? n : 0;
+}
+
+// The whole node-budget search of every slot hm_sp_begin_search left in the searching state, with the native evaluator: two
+// persistent kernels (k_search: one workgroup per game; rise_serve: the evaluator workgroups) joined by the device-side queue of
+// hm_queue.hpp.  Replaces the host loop collect -> forward -> process of Agent::run_search's workers (agent.cc:331-352,
+// searchthread.cc:661-739); per game the order of tree operations, hence every result, is the same.  Synchronous.
+int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* search_kernel_ms) {
+    if (!sp || !net || !io) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (!io->planes[0] || !io->planes[1] || !io->value || !io->pi_a || !io->pi_b || !io->wdl || !io->moves_left
+        || !io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2) return hm_fail(HM_ERR_INVALID, "hm_sp_search needs both plane buffers and both sets of heads");
+    if (!hm_net_can_serve(net)) return hm_fail(HM_ERR_INVALID, "this network has no persistent evaluator kernel");
+    const int consumers = hm_sp_search_consumers(sp);
+    if (consumers <= 0) return hm_fail(HM_ERR_INVALID, "too many game slots for a persistent search on this device (use the lockstep calls)");
+    // The two kernels must RUN TOGETHER, so they need two hardware queues: ordinary HIP streams are multiplexed onto a small pool of
+    // queues and two of them may share one (the second kernel would then wait for the first to end — which waits for the second).
+    // Streams created with a CU mask own their queue; the mask enables every CU.
+    if (!sp->sTree) {
+        const int words = (sp->numCUs + 31) / 32;
+        std::vector<uint32_t> all((size_t)words, 0xffffffffu);
+        if (sp->numCUs % 32) all[(size_t)words - 1] = (1u << (sp->numCUs % 32)) - 1u;
+        if (hipExtStreamCreateWithCUMask(&sp->sTree, (uint32_t)words, all.data()) != hipSuccess || hipExtStreamCreateWithCUMask(&sp->sNet, (uint32_t)words, all.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            return hm_fail(HM_ERR_NO_DEVICE, "hipExtStreamCreateWithCUMask failed (persistent search needs two hardware queues)");
+        }
+    }
+    hipStream_t sT = sp->sTree, sN = sp->sNet;
+    HIPCHK(hipDeviceSynchronize());                    // planes / heads / pools may have been touched on other streams
+    if (!sp->evFork) {
+        HIPCHK(hipEventCreateWithFlags(&sp->evFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sp->evJoin, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&sp->evT0));
+        HIPCHK(hipEventCreate(&sp->evT1));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sp->h_qinit), 64, hipHostMallocDefault));
+    }
+    hmq::SrvQueue* q = reinterpret_cast<hmq::SrvQueue*>(sp->d_queue);
+    unsigned* done = reinterpret_cast<unsigned*>(sp->d_queue + sizeof(hmq::SrvQueue));
+    // every polled word starts from zero; then the two head counts (producers .. consumers are adjacent words)
+    HIPCHK(hipMemsetAsync(sp->d_queue, 0, sp->queueBytes, sT));
+    sp->h_qinit[0] = (unsigned)sp->nGames; sp->h_qinit[1] = 0u; sp->h_qinit[2] = (unsigned)consumers;
+    static_assert(offsetof(hmq::SrvQueue, error) == offsetof(hmq::SrvQueue, producers) + 4 && offsetof(hmq::SrvQueue, consumers) == offsetof(hmq::SrvQueue, producers) + 8, "queue header layout");
+    HIPCHK(hipMemcpyAsync(&q->producers, sp->h_qinit, 12, hipMemcpyHostToDevice, sT));
+    HIPCHK(hipEventRecord(sp->evFork, sT));
+    HIPCHK(hipStreamWaitEvent(sN, sp->evFork, 0));
+    hmq::ServeArgs a;
+    a.planes[0] = static_cast<const uint16_t*>(io->planes[0]); a.planes[1] = static_cast<const uint16_t*>(io->planes[1]);
+    a.value[0] = static_cast<uint16_t*>(io->value); a.value[1] = static_cast<uint16_t*>(io->value_2);
+    a.piA[0] = static_cast<uint16_t*>(io->pi_a); a.piA[1] = static_cast<uint16_t*>(io->pi_a_2);
+    a.piB[0] = static_cast<uint16_t*>(io->pi_b); a.piB[1] = static_cast<uint16_t*>(io->pi_b_2);
+    a.wdl[0] = static_cast<uint16_t*>(io->wdl); a.wdl[1] = static_cast<uint16_t*>(io->wdl_2);
+    a.ml[0] = static_cast<uint16_t*>(io->moves_left); a.ml[1] = static_cast<uint16_t*>(io->moves_left_2);
+    a.q = q; a.done = done;
+    a.clkSum = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->sumN); a.clkCnt = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->cntN);   // the evaluator's ticks / positions
+    // the evaluator first: its workgroups only ever wait for the games, never the other way round before a game has work for them
+    if (int rc = hm_net_serve(net, a, consumers, sN)) return rc;
+    SearchIo sio;
+    sio.planes[0] = static_cast<uint16_t*>(io->planes[0]); sio.planes[1] = static_cast<uint16_t*>(io->planes[1]);
+    for (int b = 0; b < 2; ++b) sio.out[b] = NetOut{a.value[b], a.piA[b], a.piB[b], a.wdl[b], a.ml[b]};
+    sio.q = q; sio.done = done; sio.netSel = nullptr; sio.ldsNodes = sp->searchLdsNodes;
+    (void)hipEventRecord(sp->evT0, sT);            // HIP events on the stream the kernel is launched on: its launch duration
+    hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
+    const hipError_t le = hipGetLastError();
+    (void)hipEventRecord(sp->evT1, sT);
+    if (le != hipSuccess) {
+        // the evaluator workgroups are waiting for games that never come: release them
+        sp->h_qinit[4] = 1u;
+        (void)hipMemcpyAsync(&q->error, &sp->h_qinit[4], 4, hipMemcpyHostToDevice, sT);
+        (void)hipStreamSynchronize(sT); (void)hipStreamSynchronize(sN);
+        return hm_fail(HM_ERR_NO_DEVICE, std::string("k_search launch failed: ") + hipGetErrorString(le));
+    }
+    HIPCHK(hipStreamSynchronize(sT));
+    HIPCHK(hipStreamSynchronize(sN));
+    if (search_kernel_ms) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp->evT0, sp->evT1) == hipSuccess) *search_kernel_ms = ms; else { *search_kernel_ms = 0.0; (void)hipGetLastError(); }
+    }
+    hmq::SrvQueue hq;                                              // header only (the slots follow it)
+    HIPCHK(hipMemcpy(&hq, q, offsetof(hmq::SrvQueue, slots), hipMemcpyDeviceToHost));
+    sp->lastQueueError = hq.error;
+    if (hq.error)
+        return hm_fail(HM_ERR_STATE, "persistent search gave up waiting (queue error " + std::to_string(hq.error) + "; head " + std::to_string(hq.head) + " tail "
+                       + std::to_string(hq.tail) + " producers left " + std::to_string(hq.producers) + " served " + std::to_string(hq.served) + "; search workgroups in/out "
+                       + std::to_string(hq.treesIn) + "/" + std::to_string(hq.treesOut) + " of " + std::to_string(sp->nGames) + ", evaluator workgroups in/out "
+                       + std::to_string(hq.consIn) + "/" + std::to_string(hq.consOut) + " of " + std::to_string(consumers) + "; first failed wait: game "
+                       + std::to_string((int)hq.dbg[0] - 1) + " buffer " + std::to_string(hq.dbg[1]) + " expected " + std::to_string(hq.dbg[2]) + " done " + std::to_string(hq.dbg[3])
+                       + " iteration " + std::to_string(hq.dbg[4]) + " waited ms " + std::to_string(hq.dbg[5]) + ")");
     return 0;
 }
 

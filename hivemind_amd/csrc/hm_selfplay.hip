@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/hivemind_amd.h"
+#include "hm_queue.hpp"
 
 int hm_fail(int code, const std::string& msg);
 extern "C" int hm_sp_active(hm_sp* sp, int* active);
@@ -136,6 +137,7 @@ struct hm_selfplay {
     hipEvent_t gFork = nullptr, gJoin = nullptr;
     hipEvent_t gCollected[2] = {nullptr, nullptr};
     int graphState = 0;                            // 0 not tried, 1 ready, -1 unavailable (eager loop)
+    bool persistentOff = false;                    // hm_sp_search found its kernels serialised once: lockstep from then on
     // time-managed searches (tournaments with a movetime limit): every searching slot has its own controller of the reference's
     // polling loop (agent.cc:715-806: deadline, early stopping, time extension); 0 = node-limited searches
     int moveTimeMs = 0;
@@ -358,6 +360,24 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         }
         harvested = upto;
     };
+    // Native evaluator, node-limited search, one network: the whole search is ONE launch of the persistent search kernel beside
+    // the persistent evaluator (hm_sp_search) — every game advances at its own pace instead of in lockstep iterations.
+    // HM_SELFPLAY_LOCKSTEP=1 keeps the host-driven loop below (the two produce identical records; tests compare them).
+    if (native && !s->net2 && s->moveTimeMs <= 0 && !s->persistentOff && !std::getenv("HM_SELFPLAY_LOCKSTEP")
+        && hm_sp_search_consumers(s->sp) > 0 && hm_net_can_serve(s->io.net)) {
+        double kms = 0.0;
+        const int rc = hm_sp_search(s->sp, s->io.net, &s->io, &kms);
+        if (!rc) {
+            s->res.persistent_searches += 1;
+            s->res.search_kernel_ms += kms;
+            return 0;
+        }
+        if (!hm_sp_search_not_concurrent(s->sp)) return rc;
+        // the two persistent kernels were run one after the other (e.g. under a counter-collecting profiler): this search and
+        // all later ones of this driver take the host-driven loop
+        s->persistentOff = true;
+        if (int rc2 = hm_sp_begin_again(s->sp)) return rc2;
+    }
     if (native && s->graphState == 0) build_step_graph(s, allRows);
     // Time-managed search: every 5 ms (agent.cc:562) the root statistics of all slots go through their controllers; slots told to
     // stop end at their next collect (finishing the batch in flight), the search ends when no slot is left.
@@ -560,9 +580,12 @@ static void leg_clock_begin(hm_selfplay* s) { if (s->io.net) (void)hm_sp_leg_tim
 static void leg_clock_end(hm_selfplay* s) {
     if (!s->io.net) return;
     (void)hipDeviceSynchronize();
-    double ms[3] = {0.0, 0.0, 0.0};
-    if (hm_sp_leg_times(s->sp, ms, nullptr, 1)) return;
+    double ms[3] = {0.0, 0.0, 0.0}, wait = 0.0;
+    uint64_t cnt[3] = {0, 0, 0};
+    (void)hm_sp_wait_time(s->sp, &wait);
+    if (hm_sp_leg_times(s->sp, ms, cnt, 1)) return;
     s->res.collect_ms += ms[0]; s->res.eval_ms += ms[1]; s->res.process_ms += ms[2];
+    if (s->res.persistent_searches) { s->res.search_iterations += cnt[0]; s->res.eval_batches += cnt[0]; s->res.wait_ms += wait; }   // game-iterations
 }
 
 // run_selfplay (selfplay.cc:558-748).  Whatever the outcome, the samples of every finished game are handed to the chunk

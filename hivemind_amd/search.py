@@ -56,6 +56,11 @@ _SIGS = {
     "hm_sp_set_tree_reuse": (_i, [_vp, _vp, _i]),
     "hm_sp_pv_lines": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "hm_sp_leg_clock_net": (_vp, [_vp]),
+    "hm_sp_search": (_i, [_vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "hm_sp_search_consumers": (_i, [_vp]),
+    "hm_sp_search_not_concurrent": (_i, [_vp]),
+    "hm_sp_begin_again": (_i, [_vp]),
+    "hm_sp_wait_time": (_i, [_vp, C.POINTER(C.c_double)]),
     "hm_sp_trace_select": (_i, [_i]),
     "hm_sp_trace": (_i, [_vp, _i]),
 }
@@ -161,6 +166,28 @@ class SearchEngine:
             if it % poll_every == 0 and active == 0:
                 break
         return it
+
+    def search_persistent(self, net):
+        """The whole search of every slot begin_search left searching as ONE launch of the persistent search kernel beside the
+        persistent evaluator (hm_sp_search): `net` is a FusedNet.  Same results as run(net), game by game.  -> k_search ms."""
+        from .selfplay import EvalIO
+        f16 = dict(dtype=torch.float16, device=self.device)
+        rows = self.G * BATCH
+        if not hasattr(self, "_heads2"):
+            self._heads2 = [(torch.zeros(rows, **f16), torch.zeros((rows, POLICY_VALUES), **f16), torch.zeros((rows, POLICY_VALUES), **f16),
+                             torch.zeros((rows, 3), **f16), torch.zeros(rows, **f16)) for _ in range(2)]
+        io = EvalIO()
+        io.planes[0], io.planes[1] = self.planes[0].data_ptr(), self.planes[1].data_ptr()
+        (io.value, io.pi_a, io.pi_b, io.wdl, io.moves_left) = [t.data_ptr() for t in self._heads2[0]]
+        (io.value_2, io.pi_a_2, io.pi_b_2, io.wdl_2, io.moves_left_2) = [t.data_ptr() for t in self._heads2[1]]
+        io.net = net.handle
+        torch.cuda.synchronize(self.device)
+        ms = C.c_double(0.0)
+        check(lib.hm_sp_search(self.h, net.handle, C.byref(io), C.byref(ms)))
+        return ms.value
+
+    def search_consumers(self) -> int:
+        return int(lib.hm_sp_search_consumers(self.h))
 
     def leg_times(self, reset=False):
         """Device-clock totals since the last reset: (ms[collect, forward, process], launches[3]).  Synchronise first."""

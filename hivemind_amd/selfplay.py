@@ -38,7 +38,8 @@ class SelfPlayResult(C.Structure):
                 ("collect_ms", C.c_double), ("eval_ms", C.c_double), ("process_ms", C.c_double),
                 ("nodes_visited", C.c_uint64), ("edges_scanned", C.c_uint64),
                 ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double),
-                ("chunks_flushed", C.c_uint64), ("leaf_move_words", C.c_uint64)]
+                ("chunks_flushed", C.c_uint64), ("leaf_move_words", C.c_uint64),
+                ("persistent_searches", C.c_uint64), ("search_kernel_ms", C.c_double), ("wait_ms", C.c_double)]
 
 
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)

@@ -219,6 +219,33 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
  * hm_net_forward_groups_timed with hm_sp_leg_clock_net(sp). */
 int hm_sp_leg_times(hm_sp* sp, double* ms3, uint64_t* counts3, int reset);
 uint64_t* hm_sp_leg_clock_net(hm_sp* sp);
+/* The whole node-budget search of every slot hm_sp_begin_search left searching, with the native evaluator, as TWO PERSISTENT
+ * KERNELS joined by a device-side queue (hivemind_amd/csrc/hm_queue.hpp) instead of the host loop
+ * hm_sp_collect || forward -> hm_sp_process: one workgroup per game stays alive for the search (Agent's worker loop,
+ * agent.cc:331-352, around SearchThread::run_iteration, searchthread.cc:661-739) with its node pool in LDS, and hands each
+ * collected batch to evaluator workgroups (Engine::enqueueInferenceHalf / synchronizeInferenceHalf, nn/engine.h:43-81, one
+ * position per workgroup) the moment it is written.  Per game the order of tree operations — hence every visit count — is the
+ * lockstep one; a game no longer waits for the slowest game of an iteration.  io: both plane buffers and both sets of heads
+ * (hm_eval_io of the native mode).  Synchronous (synchronises the device first); the two kernels run on two streams of the
+ * engine that own their hardware queues.  A profiler that serialises kernels (rocprofv3 --pmc) makes it give up after a few
+ * seconds with HM_ERR_STATE: profile counters on the lockstep calls (HM_SELFPLAY_LOCKSTEP=1 for the self-play driver).  Needs hm_sp_search_consumers(sp) > 0 (game slots plus
+ * at least 8 evaluator workgroups within the device's CU count) and a network with a persistent evaluator kernel (trunks of
+ * 64 / 128 / 384 channels); otherwise HM_ERR_INVALID — use the lockstep calls. */
+struct hm_net;
+struct hm_eval_io;
+int hm_sp_search(hm_sp* sp, const struct hm_net* net, const struct hm_eval_io* io,
+                 double* search_kernel_ms /* optional: duration of the k_search launch, HIP events on its stream */);
+/* 1 when the last hm_sp_search gave up because its two kernels were not running together (a profiler that serialises kernels);
+ * hm_sp_begin_again then restores the state hm_sp_begin_search had left (same targets, seeds, mask and noise; tree reuse off)
+ * so that the lockstep calls can run the search instead. */
+int hm_sp_search_not_concurrent(const hm_sp* sp);
+int hm_sp_begin_again(hm_sp* sp);
+/* Evaluator workgroups a persistent search of this engine runs (0: not available for this many game slots on this device). */
+int hm_sp_search_consumers(const hm_sp* sp);
+/* Persistent searches: total time (ms) the games spent waiting for the evaluation of their pending batches since the last
+ * hm_sp_leg_times reset.  In that mode hm_sp_leg_times reports per game-iteration sums: [0] collect phases, [2] process phases
+ * (counts = game-iterations), [1] the evaluator's time and positions. */
+int hm_sp_wait_time(hm_sp* sp, double* ms);
 /* Games still searching after the last hm_sp_process (synchronises). */
 int hm_sp_active(hm_sp* sp, int* active);
 /* Agent::root_edge_stats / root_q (agent.cc:1004-1024) for all games -> host arrays
@@ -407,6 +434,11 @@ typedef struct hm_selfplay_result {
     double   search_seconds, prologue_seconds, raw_seconds;
     uint64_t chunks_flushed;             /* chunks handed to the sink / written to the output directory */
     uint64_t leaf_move_words;            /* 4-byte move-list entries the traversal wrote for its network leaves (roofline accounting) */
+    /* persistent searches (hm_sp_search): launches of k_search, their total duration (HIP events on the launch stream) and the
+     * time the games waited for evaluations; collect_ms / process_ms are then sums over game-iterations (search_iterations counts
+     * game-iterations), eval_ms the evaluator workgroups' time over eval_rows positions */
+    uint64_t persistent_searches;
+    double   search_kernel_ms, wait_ms;
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,

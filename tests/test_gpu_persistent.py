@@ -1,0 +1,128 @@
+"""Persistent search (hm_sp_search: k_search + rise_serve joined by the device-side queue of hm_queue.hpp) against the
+host-driven lockstep loop (hm_sp_collect || forward -> hm_sp_process), which the other suites pin to the oracle: per game the
+order of tree operations is the same, so root edge lists / visits / priors / Q, node counts, collision counters and whole
+self-play records must be IDENTICAL — whatever the relative timing of games and evaluator workgroups in a given run.
+(searchthread.cc:661-739, agent.cc:331-352 are the reference loop both forms implement.)"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(seed=0):
+    from hivemind_amd import net as N
+    torch.manual_seed(seed)
+    return N.FusedNet(N.rise_v3_small())
+
+
+def _stats_equal(a, b, G):
+    for g in range(G):
+        n = a["counts"][g]
+        assert n == b["counts"][g], (g, n, b["counts"][g])
+        for k in ("move_a", "move_b", "visits"):
+            assert np.array_equal(a[k][g, :n], b[k][g, :n]), (g, k)
+        for k in ("q", "prior"):                                             # bit patterns, not tolerances
+            assert np.array_equal(a[k][g, :n].view(np.uint32), b[k][g, :n].view(np.uint32)), (g, k)
+        assert a["root_q"][g].tobytes() == b["root_q"][g].tobytes(), g
+        # status, nodes, eval rows, both collision counters, node count, root type, root visits, overflow, max depth,
+        # nodes visited / edges scanned by selection, best move, move-list words, best child's type / end
+        assert np.array_equal(a["info"][g, :16], b["info"][g, :16]), (g, a["info"][g], b["info"][g])
+
+
+@pytest.mark.parametrize("G,nodes,noise", [(24, 400, False), (48, 400, True), (64, 100, True), (8, 37, False)])
+def test_persistent_search_equals_lockstep_search(hm, G, nodes, noise):
+    net = _net()
+    roots = O.random_positions(900 + G, G * 13, 140)[::13][:G].copy()
+    roots[0] = O.Board().compact(0, False)[0]
+    seeds = (np.arange(G, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(777)
+    alpha, eps = (0.3, 0.25) if noise else (0.0, 0.0)
+    eng = hm.SearchEngine(G, 421)
+    assert eng.search_consumers() > 0
+    eng.set_games(roots)
+    eng.begin_search(nodes, seeds, alpha, eps)
+    eng.run(net)
+    want = eng.root_stats()
+    for rep in range(2):                                                     # timing differs from run to run; results must not
+        eng.set_games(roots)
+        eng.begin_search(nodes, seeds, alpha, eps)
+        ms = eng.search_persistent(net)
+        assert ms > 0.0
+        got = eng.root_stats()
+        _stats_equal(want, got, G)
+    assert int((want["info"][:, 0] == 3).sum()) >= G // 2                    # most roots really searched (ST_DONE)
+    eng.close()
+
+
+def test_persistent_search_with_masked_and_dead_slots(hm):
+    """slots that do not search (mask) leave the queue protocol intact: their workgroups only sign off"""
+    net = _net()
+    G = 16
+    roots = O.random_positions(31, G * 7, 60)[::7][:G].copy()
+    mask = (np.arange(G) % 3 != 0).astype(np.uint8)
+    eng = hm.SearchEngine(G, 200)
+    eng.set_games(roots)
+    eng.begin_search(120, None, 0.0, 0.0, mask)
+    eng.run(net)
+    want = eng.root_stats()
+    eng.set_games(roots)
+    eng.begin_search(120, None, 0.0, 0.0, mask)
+    eng.search_persistent(net)
+    _stats_equal(want, eng.root_stats(), G)
+    # no slot searching at all: both kernels start and leave
+    eng.begin_search(120, None, 0.0, 0.0, np.zeros(G, np.uint8))
+    eng.search_persistent(net)
+    eng.close()
+
+
+def test_persistent_search_without_the_lds_node_mirror(hm, monkeypatch):
+    """pools too large for LDS walk their nodes in HBM (BASELINE configs[4]: nodes = 1600); same results"""
+    net = _net()
+    G = 6
+    roots = O.random_positions(5, G * 9, 80)[::9][:G].copy()
+    eng = hm.SearchEngine(G, 1700)
+    eng.set_games(roots)
+    eng.begin_search(1600, None, 0.3, 0.25)
+    eng.run(net)
+    want = eng.root_stats()
+    eng.set_games(roots)
+    eng.begin_search(1600, None, 0.3, 0.25)
+    eng.search_persistent(net)
+    _stats_equal(want, eng.root_stats(), G)
+    eng.close()
+
+
+def _selfplay(hm, net, **kw):
+    sp = hm.SelfPlay(hm.default_selfplay_config(**kw), net)
+    res = sp.run()
+    rec, cnt = sp.records()
+    sp.close()
+    return res, rec.tobytes(), cnt
+
+
+@pytest.mark.parametrize("kw", [dict(games=16, nodes=100, seed=3, concurrent_games=16, max_macro_plies=80),
+                                dict(games=12, nodes=48, seed=11, concurrent_games=6, max_macro_plies=60)])
+def test_selfplay_records_persistent_equal_lockstep(hm, monkeypatch, kw):
+    net = _net()
+    monkeypatch.setenv("HM_SELFPLAY_LOCKSTEP", "1")
+    res_l, rec_l, cnt_l = _selfplay(hm, net, **kw)
+    assert res_l.persistent_searches == 0
+    monkeypatch.delenv("HM_SELFPLAY_LOCKSTEP")
+    res_p, rec_p, cnt_p = _selfplay(hm, net, **kw)
+    assert res_p.persistent_searches > 0 and res_p.search_kernel_ms > 0
+    assert cnt_p == cnt_l and rec_p == rec_l
+    assert (res_p.samples, res_p.total_nodes, res_p.eval_rows, res_p.nodes_visited, res_p.edges_scanned) == \
+           (res_l.samples, res_l.total_nodes, res_l.eval_rows, res_l.nodes_visited, res_l.edges_scanned)
+
+
+def test_selfplay_configs2_full_size_persistent_equals_lockstep(hm, monkeypatch):
+    """BASELINE configs[2] at full size (64 games, nodes 400, RISEv3-small): byte-identical records from both loops"""
+    net = _net()
+    kw = dict(games=64, nodes=400, seed=1, concurrent_games=64)
+    res_p, rec_p, cnt_p = _selfplay(hm, net, **kw)
+    monkeypatch.setenv("HM_SELFPLAY_LOCKSTEP", "1")
+    res_l, rec_l, cnt_l = _selfplay(hm, net, **kw)
+    assert res_p.persistent_searches > 0 and res_l.persistent_searches == 0
+    assert cnt_p == cnt_l and rec_p == rec_l
