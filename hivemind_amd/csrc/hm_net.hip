@@ -624,7 +624,8 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
 // One position through the whole network by one workgroup of 8 waves (the body of rise_forward_narrow and of the persistent
 // evaluator rise_serve): input row `pin`, outputs to row `sIdx` of the head tensors.
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
-template <int CTILES, bool K5>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
+// WT: the heads are written with write-through stores (hm_queue.hpp), the policy planes staged through LDS into 16-byte chunks.
+template <int CTILES, bool K5, bool WT = false>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
 __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __restrict__ wh, const float* __restrict__ wf, const h16* pin, size_t sIdx,
                                                 int copMax, int uHalfs, unsigned char* smem,
                                                 h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB, h16* __restrict__ wdl, h16* __restrict__ ml,
@@ -642,6 +643,7 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
     float* Pf = reinterpret_cast<float*>(U + uHalfs);                   // per-chunk parameters: b1[chunk], b2[chunk], b3[C]  (uHalfs % 8 == 0)
     h16* Pdw = reinterpret_cast<h16*>(Pf + 2 * copMax + C);             // depthwise weights [chunk][k*k]
     float* Ev = reinterpret_cast<float*>(Pdw + (((size_t)copMax * 25 + 7) & ~(size_t)7));   // ECA / head scratch: [4][C] + [C] + 64
+    h16* Pol = U + ((65 * (ldx > 88 ? ldx : 88) + 7) & ~7);             // WT: policy staging [160][64] behind Ss (host checks that U holds it)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = 8 * (lane >> 5);
     const int stile = wave & 1;                                         // the square half of every tile this wave computes
@@ -854,9 +856,19 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
                 const float mx = fmaxf(lo[0], fmaxf(lo[1], lo[2]));
                 const float e0 = __expf(lo[0] - mx), e1 = __expf(lo[1] - mx), e2 = __expf(lo[2] - mx);
                 const float inv = 1.0f / (e0 + e1 + e2);
-                value[sIdx] = (h16)((e2 - e0) * inv);
-                wdl[(size_t)sIdx * 3 + 0] = (h16)lo[0]; wdl[(size_t)sIdx * 3 + 1] = (h16)lo[1]; wdl[(size_t)sIdx * 3 + 2] = (h16)lo[2];
-                ml[sIdx] = (h16)(1.0f / (1.0f + __expf(-lo[3])));
+                const h16 hv = (h16)((e2 - e0) * inv), h0 = (h16)lo[0], h1 = (h16)lo[1], h2 = (h16)lo[2], hm = (h16)(1.0f / (1.0f + __expf(-lo[3])));
+                if constexpr (WT) {
+                    auto bits = [](h16 x) { return __builtin_bit_cast(uint16_t, x); };
+                    hmq::store2_wt(reinterpret_cast<uint16_t*>(value + sIdx), bits(hv));
+                    hmq::store2_wt(reinterpret_cast<uint16_t*>(wdl + sIdx * 3 + 0), bits(h0));
+                    hmq::store2_wt(reinterpret_cast<uint16_t*>(wdl + sIdx * 3 + 1), bits(h1));
+                    hmq::store2_wt(reinterpret_cast<uint16_t*>(wdl + sIdx * 3 + 2), bits(h2));
+                    hmq::store2_wt(reinterpret_cast<uint16_t*>(ml + sIdx), bits(hm));
+                } else {
+                    value[sIdx] = hv;
+                    wdl[(size_t)sIdx * 3 + 0] = h0; wdl[(size_t)sIdx * 3 + 1] = h1; wdl[(size_t)sIdx * 3 + 2] = h2;
+                    ml[sIdx] = hm;
+                }
             }
             __syncthreads();                                             // Y1 (inside U) is about to be overwritten by Ss
         }
@@ -884,12 +896,25 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const int ch = ct * 32 + drow(rg, lane);
-                    if (ch < 73) piA[(size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sqL] = (h16)e[rg];
-                    else if (ch < 146) piB[(size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sqL] = (h16)e[rg];
+                    if constexpr (WT) Pol[ch * 64 + sqL] = (h16)e[rg];                      // [160][64] staging behind Ss
+                    else {
+                        if (ch < 73) piA[(size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sqL] = (h16)e[rg];
+                        else if (ch < 146) piB[(size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sqL] = (h16)e[rg];
+                    }
                 }
             }
         }
         __syncthreads();
+        if constexpr (WT) {
+            // 146 planes x 64 squares = 1168 chunks of 8 halfs: one write-through 16-byte store each
+            for (int i = tid; i < 146 * 8; i += 512) {
+                const int ch = i >> 3, part = i & 7;
+                const hmq::u32x4q v = *reinterpret_cast<const hmq::u32x4q*>(Pol + ch * 64 + part * 8);
+                h16* dst = (ch < 73 ? piA + sIdx * HM_POLICY_VALUES + ch * 64 : piB + sIdx * HM_POLICY_VALUES + (ch - 73) * 64) + part * 8;
+                hmq::store16_wt(dst, v);
+            }
+            __syncthreads();                                             // Pol lies in U: the next position's input staging overwrites it
+        }
         HM_STAMP();
     }
 }
@@ -937,13 +962,12 @@ __global__ __launch_bounds__(512, 1) void rise_serve(const NetDesc* __restrict__
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const int g = hmq::item_game(it), buf = hmq::item_buf(it), row = hmq::item_row(it);
         const size_t r = (size_t)g * 8 + row;
-        narrow_position<CTILES, K5>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
+        narrow_position<CTILES, K5, true>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
                                     reinterpret_cast<h16*>(a.value[buf]), reinterpret_cast<h16*>(a.piA[buf]), reinterpret_cast<h16*>(a.piB[buf]),
                                     reinterpret_cast<h16*>(a.wdl[buf]), reinterpret_cast<h16*>(a.ml[buf]), nullptr, dbgN);
-        hmq::drain_stores();                                        // every wave stored part of the heads
+        hmq::drain_stores();                                        // every wave's write-through stores of the heads have left
         __syncthreads();                                            // (also: every thread has read s_item)
         if (threadIdx.x == 0) {
-            hmq::release_agent();
             __hip_atomic_fetch_add(&a.done[g * 2 + buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticks += __builtin_amdgcn_s_memrealtime() - t0; ++count;
         }
@@ -1002,10 +1026,15 @@ static hipError_t with_narrow(const hm_net* net, F f) {
     if (net->nd.C == 384) return net->k5 ? f(rise_forward_narrow<12, true>) : f(rise_forward_narrow<12, false>);
     return net->k5 ? f(rise_forward_narrow<4, true>) : f(rise_forward_narrow<4, false>);
 }
-int hm_net_can_serve(const hm_net* net) { return net && net->narrow ? 1 : 0; }
+int hm_net_can_serve(const hm_net* net) {
+    if (!net || !net->narrow) return 0;
+    const int ldx = net->nd.C + 8;
+    const int polOff = (65 * std::max(ldx, 88) + 7) & ~7;            // narrow_position's Pol: behind Ss inside the union region
+    return polOff + 160 * 64 <= net->uHalfs ? 1 : 0;
+}
 int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t st) {
     using namespace hmn;
-    if (!net || !net->narrow || grid <= 0) return hm_fail(HM_ERR_INVALID, "hm_net_serve: this network has no persistent evaluator kernel");
+    if (!hm_net_can_serve(net) || grid <= 0) return hm_fail(HM_ERR_INVALID, "hm_net_serve: this network has no persistent evaluator kernel");
     auto launch = [&](auto kern) {
         static_cast<void>(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->ldsNarrow));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), net->ldsNarrow, st, net->d_nd, static_cast<const h16*>(net->d_wh), static_cast<const float*>(net->d_wf),

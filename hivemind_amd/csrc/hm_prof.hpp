@@ -3,12 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #ifdef HM_SEARCH_PROF
-__shared__ unsigned long long s_prof[64];
+constexpr int HM_NPROF = 64;                 // probe slots: sums in [0, NPROF), call counts in [NPROF, 2 NPROF)
+__shared__ unsigned long long s_prof[2 * HM_NPROF];
 #define PROF_T(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
-#define PROF_ADD(slot, t) do { if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[slot] += __builtin_amdgcn_s_memtime() - (t); s_prof[32 + (slot)]++; } } while (0)
-#define PROF_ADD_T(slot, t, tid) do { if (blockIdx.x == 0 && threadIdx.x == (tid)) { s_prof[slot] += __builtin_amdgcn_s_memtime() - (t); s_prof[32 + (slot)]++; } } while (0)
-#define PROF_INIT() do { if (threadIdx.x < 64) s_prof[threadIdx.x] = 0; __syncthreads(); } while (0)
-#define PROF_FLUSH() do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 64) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
+#define PROF_ADD(slot, t) do { if (blockIdx.x == 0 && threadIdx.x == 0) { s_prof[slot] += __builtin_amdgcn_s_memtime() - (t); s_prof[HM_NPROF + (slot)]++; } } while (0)
+#define PROF_ADD_T(slot, t, tid) do { if (blockIdx.x == 0 && threadIdx.x == (tid)) { s_prof[slot] += __builtin_amdgcn_s_memtime() - (t); s_prof[HM_NPROF + (slot)]++; } } while (0)
+#define PROF_INIT() do { if (threadIdx.x < 2 * HM_NPROF) s_prof[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define PROF_FLUSH() do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x < 2 * HM_NPROF) g_prof[threadIdx.x] += s_prof[threadIdx.x]; } while (0)
 #else
 #define PROF_T(t) do {} while (0)
 #define PROF_ADD(slot, t) do {} while (0)

@@ -8,10 +8,9 @@
 // starts on a batch the moment its game has written it.  The order of tree operations per game — hence every result — is unchanged.
 //
 // Protocol (MI355X: 8 XCDs with private L2s, per-CU L1 never refreshed by other CUs' stores; cdna_hip_programming.md Guideline 16):
-//   producer of bulk data (plane rows + move lists, or the network heads): plain stores; EVERY storing wave drains (s_waitcnt
-//   vmcnt(0)); workgroup barrier; ONE lane: agent-scope release fence, drain again (the compiler may drop the fence's own wait),
-//   then the signal — an 8-byte {ticket tag, payload} granule stored with a relaxed agent-scope atomic (queue slot), or an
-//   agent-scope atomic add (completion counter);
+//   producer of bulk data (plane rows, or the network heads): WRITE-THROUGH stores (sc1: store16_wt / store2_wt), so no release
+//   fence; EVERY storing wave drains (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane signals — an 8-byte {ticket tag, payload}
+//   granule stored with a relaxed agent-scope atomic (queue slot), or an agent-scope atomic add (completion counter);
 //   consumer: ONE lane polls the ONE word relaxed (s_sleep between polls), then ONE agent-scope acquire fence + drain, workgroup
 //   barrier, then plain loads by every wave.
 //   Every polled word is zeroed by a hipMemsetAsync ahead of the launches; tags / counters count within one search.
@@ -61,6 +60,15 @@ __device__ __forceinline__ void acquire_agent() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// Write-through (sc1) stores for bytes another workgroup will read inside the launch: they leave the XCD's L2 at once, so the
+// hand-off needs no release fence — which writes back a whole L2 and, issued once per position by a hundred workgroups, was
+// measured to stretch the evaluator's 0.075 ms per position to 0.5 ms.  16 bytes per lane; the asm store is invisible to the
+// compiler's wait counting: the storing wave runs drain_stores() before it signals.
+typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(void* p, u32x4q v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store2_wt(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, HMQ_RLX); }
 __device__ __forceinline__ bool spin_expired(u64q t0) { return (u64q)__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS; }
 
 // producer, ONE lane (release done): n items with consecutive tickets

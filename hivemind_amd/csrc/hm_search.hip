@@ -182,7 +182,7 @@ struct Pools {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
-__device__ unsigned long long g_prof[64];      // hm_prof.hpp probes (all zero in the product build)
+__device__ unsigned long long g_prof[128];     // hm_prof.hpp probes: 64 sums + 64 call counts (all zero in the product build)
 #ifdef HM_SEARCH_PROF
 constexpr int PROF_LAUNCHES = 8192;
 __device__ unsigned int g_colDur[PROF_LAUNCHES][64];   // traversal cycles of wave 0 per (k_collect launch, game slot < 64): straggler analysis
@@ -890,6 +890,8 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
 }
 
 // ---- leaf planes: wave-cooperative board_to_planes (fp16) for one hm_board in LDS ----------
+// WT: write-through stores (hm_queue.hpp) — the rows are read by another workgroup (the persistent evaluator) inside the launch
+template <bool WT = false>
 __device__ inline void write_planes_f16(const RulesTab& rt, const u64* bw /*26 words, LDS*/, uint4* dst, u64* s_mask, uint32_t* s_val) {
     const int lane = threadIdx.x & 63;
     const u64 tail = bw[25];
@@ -942,7 +944,8 @@ __device__ inline void write_planes_f16(const RulesTab& rt, const u64* bw /*26 w
         o.y = ((b & 4) ? v : 0) | ((b & 8) ? v << 16 : 0);
         o.z = ((b & 16) ? v : 0) | ((b & 32) ? v << 16 : 0);
         o.w = ((b & 64) ? v : 0) | ((b & 128) ? v << 16 : 0);
-        dst[c] = o;
+        if constexpr (WT) { hmq::u32x4q w; w.x = o.x; w.y = o.y; w.z = o.z; w.w = o.w; hmq::store16_wt(&dst[c], w); }
+        else dst[c] = o;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -1072,7 +1075,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         for (int i = lane; i < n + 1; i += 64) pr[i] = (float)((double)pr[i] / sum);
         __builtin_amdgcn_wave_barrier();
     }
-    PROF_ADD(22, te2);
+    PROF_ADD_T(40, te2, 64);
     // root Dirichlet noise (node.h:286-315): gamma draws were made on the host
     Node leaf = s.nodes[ctx.leaf];
     if (leaf.depth == 0 && s.g->alpha > 0.0f && s.g->eps > 0.0f) {
@@ -1126,7 +1129,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
         }
     }
     wave_fence();
-    PROF_ADD(23, te3);
+    PROF_ADD_T(41, te3, 64);
     PROF_T(te4);
     h.movesA = offM[0]; h.movesB = offM[1]; h.priorsA = offP[0]; h.priorsB = offP[1];
     gen_push(s, h, 0, 0);
@@ -1154,7 +1157,7 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     np->more = h.heapSize > 0;
     wave_fence();
     if ((leaf.flags & F_EXPANDED) && lane == 0) node_set_flag(np, F_EXPANDED);
-    PROF_ADD(24, te4);
+    PROF_ADD_T(42, te4, 64);
 }
 
 __device__ inline float shape_value(const G& s, uint16_t valueH, const uint16_t* wdl, uint16_t mlH) {   // searchthread.cc:569-619
@@ -1535,6 +1538,7 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
 
 // The three helper waves of a game's collect phase (k_collect and the persistent k_search): classifier (wave 1), plane writer
 // (wave 2), generator (wave 3).  Each returns once the traversal wave has raised svcStop and every request has been served.
+template <bool WT = false>
 __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, WaveLds& L, const Pools& pl, const Game& s_game, int g, uint16_t* planesNext, int wave) {
     if (wave == 1) {
         // classifier: serves the traversal's leaf requests in order; ends once the traversal has stopped and every request is served
@@ -1597,7 +1601,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 if (served >= posted) break;
             }
             const int img = served & (BATCH - 1), row = L.postRow[img];
-            write_planes_f16(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
+            write_planes_f16<WT>(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
             leaf_move_list(pl, s_rt, L, g, img, row, 0);
             served++;
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1770,6 +1774,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     __shared__ SearchCtl s_ctl;
     __shared__ unsigned s_expect[2];                                // rows published per buffer so far
     const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PROF_INIT();
     G s = make_view(pl, prm, g);
     Game* const gGame = s.g;
     Node* const gNodes = s.nodes;
@@ -1826,21 +1831,32 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
             tW += t1 - t0; t0 = t1;
         }
+        PROF_T(tpw);
         __syncthreads();
+        PROF_ADD(35, tpw);
+        PROF_T(tpp);
         if (!s_ctl.ok) return false;
         const int nctx = s_game.ctxCount[pending];
         __syncthreads();                                            // every wave holds the batch header before wave 0 retires it
         if (wave == 0) {
+            PROF_T(tpb);
             if (abortIt) abort_batch(s, pending);                   // discard_pending_iteration (agent.cc:343-352)
             else backup_batch(s, pending, &io.out[pending], rowBase);
-        } else if (!abortIt) expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase);
+            PROF_ADD(37, tpb);
+        } else if (!abortIt) {
+            PROF_T(tpe);
+            expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase);
+            PROF_ADD_T(43, tpe, 64);
+        }
         __threadfence_block();
         __syncthreads();
+        PROF_ADD(36, tpp);
         if (threadIdx.x == 0) tP += __builtin_amdgcn_s_memrealtime() - t0;
         return true;
     };
     for (;;) {
         // ---- control: worker loop (agent.cc:331-341) + run_iteration head (searchthread.cc:661-678)
+        PROF_T(tct);
         if (threadIdx.x == 0) {
             const bool fin = s_game.nodesSearched >= s_game.targetNodes || s.nodes[s_game.root].type != T_UNSOLVED || s_game.overflow;
             const bool first = s_game.pending < 0;
@@ -1852,6 +1868,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
         }
         __syncthreads();
+        PROF_ADD(38, tct);
         if (s_ctl.action == ACT_FINISH) {
             // finish_pending / discard_pending_iteration (agent.cc:343-352)
             bool ok = true;
@@ -1871,17 +1888,22 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         u64 t0 = 0;
         if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
         // ---- collect phase (collect_batch, searchthread.cc:255-442) into plane buffer `buf`
+        PROF_T(tcp);
         if (wave == 0) {
             s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0;
             collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
             if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else collect_helper_role(s, s_rt, L, pl, s_game, g, io.planes[buf], wave);
-        hmq::drain_stores();                                        // plane rows and move lists of this batch have left every wave
+        } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave);
+        PROF_ADD(33, tcp);
+        PROF_T(tcd);
+        hmq::drain_stores();                                        // the write-through stores of this batch's plane rows have left every wave
         __syncthreads();
+        PROF_ADD(39, tcd);
+        PROF_ADD(32, tcp);
+        PROF_T(tpu);
         if (threadIdx.x == 0) {
             const int valid = s_game.validCount[buf];
             if (valid > 0) {                                        // hand the batch to the evaluator
-                hmq::release_agent();
                 unsigned items[BATCH];
                 const int net = io.netSel ? io.netSel[g] : 0;
                 for (int r = 0; r < valid; ++r) items[r] = hmq::item_pack(g, buf, r, net);
@@ -1891,6 +1913,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
             tC += t1 - t0; nIt++;
         }
+        PROF_ADD(34, tpu);
         if (first) {
             // with nothing in flight the first batch went to buffer 0 and its lookahead follows
             if (wave == 0) {
@@ -1906,6 +1929,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             if (threadIdx.x == 0) { s_game.overflow |= 128; s_game.pending = -1; s_game.status = ST_ERROR; }
             break;
         }
+        PROF_T(ttl);
         if (wave == 0) {                                            // run_iteration tail
             const int look = 1 - s_game.pending;
             if (lane == 0) s_game.pending = -1;
@@ -1914,6 +1938,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             else if (lane == 0) s_game.pending = look;
         }
         __syncthreads();
+        PROF_ADD(45, ttl);
     }
     __syncthreads();
     // ---- write the tree and the game record back; the last search workgroup to leave releases the evaluator
@@ -1934,6 +1959,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         __hip_atomic_fetch_add(&io.q->treesOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hmq::producer_exit(io.q);
     }
+    PROF_FLUSH();
 }
 
 // Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
@@ -3112,8 +3138,8 @@ int hm_sp_trace(unsigned long long* out, int cap) {
 }
 // diagnostic (all zeros unless built with -DHM_SEARCH_PROF): out[0..31] cycles, out[32..63] counts; reset != 0 clears
 int hm_sp_profile(unsigned long long* out64, int reset) {
-    if (out64) HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));
-    if (reset) { unsigned long long z[64] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
+    if (out64) HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 128));       // 64 sums, then 64 call counts
+    if (reset) { unsigned long long z[128] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z)); }
     return HM_OK;
 }
 int hm_sp_profile_launches(unsigned int* out, int launches) {   // [launches][64] traversal cycles per k_collect launch and game slot

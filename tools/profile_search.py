@@ -24,7 +24,7 @@ hm.init(0)
 torch.manual_seed(0)
 fn = _lib.lib.hm_sp_profile
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
-buf = np.zeros(64, dtype=np.uint64)
+buf = np.zeros(128, dtype=np.uint64)
 cfg = hm.default_selfplay_config(games=games, nodes=nodes, seed=1, concurrent_games=games, max_macro_plies=int(os.environ.get("PLIES", 40)))
 sp = hm.SelfPlay(cfg, N.FusedNet(N.rise_v3_small()))
 fn(None, 1)
@@ -33,13 +33,20 @@ fn(buf.ctypes.data, 0)
 names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "select_child(puct)", "jb_make", "canonicalize_child",
          "classify_terminal", "hash+store+planes", "ctx/traj store", "stage_table", "k_collect total", "process: expand phase", "process: total", "path_reset", "process: backup_batch",
          "classifier wave: load + history", "classify: checkmate x2", "classify: draw", "classify: waiting-board mate", "wait: classifier wave", "puct: arg-max loop",
-         "wait: generator wave", "wait: classifier (join)", "classifier wave: request total", "classifier wave: until type ack", "k_collect: drain (block join)", "k_collect: write-back", "position_child: path_load", "position_child: path_store", "scan_edges"]
+         "wait: generator wave", "wait: classifier (join)", "classifier wave: request total", "classifier wave: until type ack", "k_collect: drain (block join)", "k_collect: write-back", "position_child: path_load", "position_child: path_store", "scan_edges",
+         "(clock ticks)", "(clock ticks)",
+         "k_search: collect phase", "k_search: collect_batch (wave 0)", "k_search: publish", "k_search: wait for evaluation", "k_search: process phase",
+         "k_search: backups (wave 0)", "k_search: control", "k_search: drain + barrier", "expand: gather + softmax (wave 1)", "expand: sort + store (wave 1)",
+         "expand: frontier + first child (wave 1)", "k_search: expansions (wave 1)", "-", "k_search: iteration tail"]
 it = res.search_iterations
+if res.persistent_searches:
+    it = max(1, int(buf[64 + 32]))          # game slot 0 only: its own iterations
+    print(f"persistent searches {res.persistent_searches}: per-iteration figures are for game slot 0 ({it} iterations); wait_ms {res.wait_ms:.1f} k_search ms {res.search_kernel_ms:.1f}")
 print(f"samples {res.samples} iters {it} pos/s {res.samples / res.seconds:.1f}")
 if int(buf[31]):
     print(f"k_collect shader clock: {int(buf[30]) / int(buf[31]) * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
 for i, n in enumerate(names):
-    cyc, cnt = int(buf[i]), int(buf[32 + i])
+    cyc, cnt = int(buf[i]), int(buf[64 + i])
     print(f"{n:28s} cycles/iter {cyc / max(it, 1):10.0f}   calls/iter {cnt / max(it, 1):6.2f}   cycles/call {cyc / max(cnt, 1):9.0f}")
 
 # straggler analysis: wave-0 traversal cycles per (k_collect launch, game slot); a launch lasts as long as its slowest game
