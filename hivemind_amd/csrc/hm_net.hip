@@ -24,6 +24,7 @@
 
 #include "../../include/hivemind_amd.h"
 #include "hm_queue.hpp"
+#include "hm_policy.hpp"
 
 int hm_fail(int code, const std::string& msg);
 
@@ -625,11 +626,14 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
 // evaluator rise_serve): input row `pin`, outputs to row `sIdx` of the head tensors.
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
 // WT: the heads are written with write-through stores (hm_queue.hpp), the policy planes staged through LDS into 16-byte chunks.
-template <int CTILES, bool K5, bool WT = false>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
+// PolicyEpi (WT only): called by every thread with the staged logits `pol` ([160][64] fp16 in LDS: board A's 73 planes, then board
+// B's) and `scratch` (the LDS behind them) in place of storing the logits; it ends with a workgroup barrier of its own.
+struct NoPolicyEpi { static constexpr bool present = false; __device__ void operator()(const h16*, unsigned char*) const {} };
+template <int CTILES, bool K5, bool WT = false, typename PolicyEpi = NoPolicyEpi>      // CTILES = C / 32 (2, 4 or 12); cin_pad must be 80
 __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __restrict__ wh, const float* __restrict__ wf, const h16* pin, size_t sIdx,
                                                 int copMax, int uHalfs, unsigned char* smem,
                                                 h16* __restrict__ value, h16* __restrict__ piA, h16* __restrict__ piB, h16* __restrict__ wdl, h16* __restrict__ ml,
-                                                unsigned long long* __restrict__ dbg, int& dbgN) {
+                                                unsigned long long* __restrict__ dbg, int& dbgN, PolicyEpi epi = PolicyEpi()) {
     // C = 64, 128 or 384: an N = C GEMM is CTILES column tiles x 2 square tiles = 2*CTILES tiles of 32x32 over 8 waves, i.e.
     // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
     // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
@@ -905,7 +909,9 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
             }
         }
         __syncthreads();
-        if constexpr (WT) {
+        if constexpr (WT && PolicyEpi::present) {
+            epi(Pol, reinterpret_cast<unsigned char*>(Pol + 160 * 64));
+        } else if constexpr (WT) {
             // 146 planes x 64 squares = 1168 chunks of 8 halfs: one write-through 16-byte store each
             for (int i = tid; i < 146 * 8; i += 512) {
                 const int ch = i >> 3, part = i & 7;
@@ -937,6 +943,46 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
     if (clk && threadIdx.x == 0) atomicMax(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
+// The prior pipeline of an evaluated leaf (hm_policy.hpp) on the logits still in LDS: wave 0 serves board A, wave 1 board B — legal
+// moves in from the search workgroup's list, moves and priors in prior order out (write-through, 16 bytes per lane) to the arrays
+// the search workgroup copies into its tree.  The 18.7 KB of logits per position are never written to HBM.
+constexpr int PRIOR_SCRATCH_BYTES = 2 * (HM_MAX_MOVES * 4 + (HM_MAX_MOVES + 8) * 4 + HM_MAX_MOVES * 4 + HM_MAX_MOVES * 4);
+struct PriorEpi {
+    static constexpr bool present = true;
+    const hmq::ServeArgs* a;
+    size_t slot;             // (game * 2 + buffer) * 8 + row: index of this leaf's lists
+    int game;
+    bool root;
+    __device__ __forceinline__ void operator()(const h16* pol, unsigned char* scratch) const {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wave < 2) {
+            const int b = wave;
+            unsigned char* base = scratch + (size_t)b * (PRIOR_SCRATCH_BYTES / 2);
+            uint32_t* list = reinterpret_cast<uint32_t*>(base);
+            float* pr = reinterpret_cast<float*>(list + HM_MAX_MOVES);           // (the list's MOVE_NONE may land in pr[0]'s place only at n = 512: lists are < 512)
+            uint32_t* outM = reinterpret_cast<uint32_t*>(pr + HM_MAX_MOVES + 8);
+            float* outP = reinterpret_cast<float*>(outM + HM_MAX_MOVES);
+            const int cnt = a->leafCounts[slot * 2 + b];
+            const int n = cnt & 0xffff, stm = (cnt >> 16) & 1;
+            const uint32_t* src = a->leafMoves + (slot * 2 + b) * HM_MAX_MOVES;
+            for (int i = lane; i < n; i += 64) list[i] = src[i];
+            __builtin_amdgcn_wave_barrier();
+            const h16* head = pol + (b ? 73 * 64 : 0);
+            const float* nz = (root && a->noiseOn) ? a->noise + ((size_t)game * 2 + b) * hmp::NOISE_CAP : nullptr;
+            const int nAct = hmp::board_priors_sorted(list, pr, n, stm, a->polNormal, a->polDrop,
+                                                      [head](int idx) { return __builtin_bit_cast(uint16_t, head[idx]); }, nz, a->noiseEps, outM, outP);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* dm = a->sortedMoves + (slot * 2 + b) * HM_MAX_MOVES;
+            float* dp = a->sortedPriors + (slot * 2 + b) * HM_MAX_MOVES;
+            for (int c = lane; c * 4 < nAct; c += 64) {                          // 16-byte chunks (the rows are 2 KB, 16-byte aligned)
+                hmq::store16_wt(dm + c * 4, *reinterpret_cast<const hmq::u32x4q*>(outM + c * 4));
+                hmq::store16_wt(dp + c * 4, *reinterpret_cast<const hmq::u32x4q*>(outP + c * 4));
+            }
+        }
+        __syncthreads();                                             // the scratch lies in the union region the next position stages into
+    }
+};
+
 // Persistent evaluator (hm_queue.hpp): every workgroup takes one position at a time from the device-side queue the search
 // workgroups fill, runs the whole network on it and signals the owning game, until the queue hands it IT_POISON.  Replaces
 // the per-iteration forward launch of the lockstep loop: a batch is evaluated as soon as its game has written it, eight
@@ -962,9 +1008,10 @@ __global__ __launch_bounds__(512, 1) void rise_serve(const NetDesc* __restrict__
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const int g = hmq::item_game(it), buf = hmq::item_buf(it), row = hmq::item_row(it);
         const size_t r = (size_t)g * 8 + row;
-        narrow_position<CTILES, K5, true>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
-                                    reinterpret_cast<h16*>(a.value[buf]), reinterpret_cast<h16*>(a.piA[buf]), reinterpret_cast<h16*>(a.piB[buf]),
-                                    reinterpret_cast<h16*>(a.wdl[buf]), reinterpret_cast<h16*>(a.ml[buf]), nullptr, dbgN);
+        PriorEpi epi{&a, (size_t)(g * 2 + buf) * 8 + row, g, (it & hmq::IT_ROOT) != 0};
+        narrow_position<CTILES, K5, true, PriorEpi>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
+                                                    reinterpret_cast<h16*>(a.value[buf]), reinterpret_cast<h16*>(a.piA[buf]), reinterpret_cast<h16*>(a.piB[buf]),
+                                                    reinterpret_cast<h16*>(a.wdl[buf]), reinterpret_cast<h16*>(a.ml[buf]), nullptr, dbgN, epi);
         hmq::drain_stores();                                        // every wave's write-through stores of the heads have left
         __syncthreads();                                            // (also: every thread has read s_item)
         if (threadIdx.x == 0) {
@@ -1030,7 +1077,7 @@ int hm_net_can_serve(const hm_net* net) {
     if (!net || !net->narrow) return 0;
     const int ldx = net->nd.C + 8;
     const int polOff = (65 * std::max(ldx, 88) + 7) & ~7;            // narrow_position's Pol: behind Ss inside the union region
-    return polOff + 160 * 64 <= net->uHalfs ? 1 : 0;
+    return polOff + 160 * 64 + hmn::PRIOR_SCRATCH_BYTES / 2 <= net->uHalfs ? 1 : 0;     // + the prior pipeline's scratch (PriorEpi)
 }
 int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t st) {
     using namespace hmn;

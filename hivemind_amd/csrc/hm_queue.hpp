@@ -28,6 +28,7 @@ constexpr u64q MEET_LIMIT_TICKS = 300000000ULL;    // 3 s: by then the other ker
 
 // item payload (low 32 bits of a slot): game slot, plane buffer, row, evaluator-specific flags
 constexpr unsigned IT_POISON = 0x80000000u;  // no more work: the consumer leaves
+constexpr unsigned IT_ROOT = 0x02000000u;    // the leaf is the root of its search: Dirichlet noise is mixed into its priors
 __host__ __device__ inline unsigned item_pack(int game, int buf, int row, int net) { return (unsigned)game | ((unsigned)buf << 20) | ((unsigned)row << 21) | ((unsigned)net << 24); }
 __host__ __device__ inline int item_game(unsigned it) { return (int)(it & 0xfffffu); }
 __host__ __device__ inline int item_buf(unsigned it) { return (int)((it >> 20) & 1u); }
@@ -127,6 +128,17 @@ struct ServeArgs {
     uint16_t* ml[2];
     SrvQueue* q;
     unsigned* done;
+    // the prior pipeline of every evaluated leaf runs on the evaluator (hm_policy.hpp): legal move lists in (tree -> evaluator),
+    // moves and priors in prior order out; the policy logits themselves never leave the workgroup's LDS
+    const uint32_t* leafMoves;               // [games][2][8][2][HM_MAX_MOVES], bit 31 = capture
+    const int* leafCounts;                   // [games][2][8][2]: moves | side to move << 16
+    uint32_t* sortedMoves;                   // [games][2][8][2][HM_MAX_MOVES]
+    float* sortedPriors;
+    const int* polNormal;                    // policy index tables (common/globals.cc:50-103)
+    const int* polDrop;
+    const float* noise;                      // [games][2][NOISE_CAP] gamma draws of the roots
+    int noiseOn;
+    float noiseEps;
     u64q* clkSum;                            // += ticks (100 MHz) spent evaluating, or nullptr
     u64q* clkCnt;                            // += positions evaluated
 };

@@ -45,6 +45,7 @@ __device__ int g_traceGame = -1;
 #include "hm_rules_device.hpp"
 #include "hm_host.hpp"
 #include "hm_queue.hpp"
+#include "hm_policy.hpp"
 
 using namespace hmd;
 
@@ -57,7 +58,7 @@ namespace hms {
 constexpr int BATCH = 8;                 // SearchParams::BATCH_SIZE
 constexpr int MAX_TRAJ = 96;             // search path cap (root .. leaf)
 constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown to the run's macro-ply limit, hm_sp_create_ex)
-constexpr int NOISE_CAP = 320;           // > max actions per board (304 + pass)
+constexpr int NOISE_CAP = hmp::NOISE_CAP; // > max actions per board (304 + pass)
 constexpr int MIN_VISITS_TAB = 1 << 15;  // cpuct / PW tables: at least this long; sized from the node budget (Params::tabLen)
 constexpr int NLISTS = 8;                // LDS scratch move lists per wave
 constexpr int COLLECT_THREADS = 256;     // k_collect: traversal wave, classifier wave, plane-writer wave, generator wave
@@ -168,7 +169,9 @@ struct Pools {
     u64* hist;            // [nGames][2][histCap]
     float* noise;         // [nGames][2][NOISE_CAP]
     u32* leafMoves;       // [nGames][2 batches][BATCH rows][2 boards][HM_MAX_MOVES]: filtered legal lists of the network leaves
-    int* leafCounts;      // [nGames][2][BATCH][2]
+    int* leafCounts;      // [nGames][2][BATCH][2]: moves kept | side to move << 16
+    u32* sortedMoves;     // [nGames][2][BATCH][2][HM_MAX_MOVES]: persistent evaluator -> tree, moves (+ capture bit) in prior order
+    float* sortedPriors;  // same shape: their priors
     const float* cpuctTab;   // [Params::tabLen]
     const int* pwRoot;       // [Params::tabLen]
     const int* pwNode;
@@ -194,36 +197,7 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// exp for x <= 0 from IEEE +,*,fma,rint only (identical copy: oracle/search.hpp portable_expf)
-__device__ __forceinline__ float hm_expf(float x) {
-    if (!(x > -87.0f)) return 0.0f;
-    if (x > 0.0f) x = 0.0f;
-    const float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(-n, 0.693145751953125f, x);
-    r = __builtin_fmaf(-n, 1.42860682030941723212e-6f, r);
-    float p = 1.9875691500e-4f;
-    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-    p = __builtin_fmaf(p * r, r, r) + 1.0f;
-    int bits = __float_as_int(p);
-    bits += (int)n << 23;
-    return __int_as_float(bits);
-}
-__device__ __forceinline__ float h2f(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31;
-    uint32_t m = h & 0x3ffu, x;
-    if (e == 0) {
-        if (m == 0) x = sign;
-        else { int s = 0; while (!(m & 0x400u)) { m <<= 1; ++s; } m &= 0x3ffu; x = sign | ((uint32_t)(113 - s) << 23) | (m << 13); }
-    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
-    else x = sign | ((e + 112) << 23) | (m << 13);
-    return __int_as_float((int)x);
-}
-__device__ __forceinline__ bool finite_f(float v) { return (__float_as_int(v) & 0x7f800000) != 0x7f800000; }
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(hi, fmaxf(lo, v)); }
+using hmp::hm_expf; using hmp::h2f; using hmp::finite_f; using hmp::clampf; using hmp::board_priors_sorted;   // hm_policy.hpp (shared with the persistent evaluator)
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ULL; }
 __device__ __forceinline__ bool wave_all(bool p) { return __ballot(!p) == 0ULL; }
@@ -950,6 +924,7 @@ __device__ inline void write_planes_f16(const RulesTab& rt, const u64* bw /*26 w
     __builtin_amdgcn_wave_barrier();
 }
 
+struct PreSorted { const u32* moves; const float* priors; };   // this game's [2][BATCH][2][HM_MAX_MOVES] arrays sorted by the persistent evaluator
 struct ExpLds {          // per-wave scratch of expand_leaf
     u32 lists[2][HM_MAX_MOVES];
     float priors[2][HM_MAX_MOVES + 8];
@@ -1009,7 +984,8 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
 // process of one context list (searchthread.cc:444-639).  outs == nullptr for terminal-only batches.
 struct NetOut { const uint16_t *value, *piA, *piB, *wdl, *ml; };
 
-__device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int buf, int row, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB) {
+__device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ctx& ctx, int buf, int row, int rootTeam, bool rootAdv, const uint16_t* piA, const uint16_t* piB,
+                                   const PreSorted* pre = nullptr) {
     const int lane = threadIdx.x & 63;
     P bd[2];
     {
@@ -1025,76 +1001,18 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     int nReal[2];
     {
         const int* cnt = s.leafCounts + ((size_t)buf * BATCH + row) * 2;
-        nReal[0] = cnt[0]; nReal[1] = cnt[1];
+        nReal[0] = cnt[0] & 0xffff; nReal[1] = cnt[1] & 0xffff;                // (bit 16: the board's side to move, for the evaluator)
         const u32* src = s.leafMoves + ((size_t)buf * BATCH + row) * 2 * HM_MAX_MOVES;
-        for (int b = 0; b < 2; ++b)
-            for (int i = lane; i < nReal[b]; i += 64) L.lists[b][i] = src[(size_t)b * HM_MAX_MOVES + i];
+        if (!pre)
+            for (int b = 0; b < 2; ++b)
+                for (int i = lane; i < nReal[b]; i += 64) L.lists[b][i] = src[(size_t)b * HM_MAX_MOVES + i];
     }
     __builtin_amdgcn_wave_barrier();
     PROF_T(te2);
-    int nAct[2];
-    for (int b = 0; b < 2; ++b) {
-        u32* list = L.lists[b];
-        float* pr = L.priors[b];
-        const int n = nReal[b];
-        list[n] = 0;                                           // MOVE_NONE appended last
-        nAct[b] = n + 1;
-        __builtin_amdgcn_wave_barrier();
-        if (n == 0) { pr[0] = 1.0f; __builtin_amdgcn_wave_barrier(); continue; }
-        // get_normalized_probability (utils.h:226-243): gather fp16 logits through the policy tables
-        const uint16_t* pol = b == 0 ? piA : piB;
-        const int stm = (int)(b ? bd[1].stm : bd[0].stm);
-        float mx = -INFINITY;
-        for (int i = lane; i < n + 1; i += 64) {
-            const u32 m = list[i];
-            int idx;
-            if (m == 0) idx = 0;
-            else if ((m & (15u << 12)) == HM_MT_DROP) idx = s.pl->polDrop[(stm * 64 + (m & 63)) * 8 + ((m >> 16) & 63)];
-            else {
-                const int f = (m >> 6) & 63, to = m & 63;
-                const int knight = ((m & (15u << 12)) == HM_MT_PROMOTION && ((m >> 16) & 63) == HM_KNIGHT) ? 1 : 0;
-                idx = s.pl->polNormal[((stm * 64 + f) * 64 + to) * 2 + knight];
-            }
-            const float lg = idx >= 0 ? h2f(pol[idx]) : -INFINITY;
-            pr[i] = lg;
-            if (finite_f(lg)) mx = fmaxf(mx, lg);
-        }
-        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        mx = ufirstf(mx);
-        __builtin_amdgcn_wave_barrier();
-        if (!finite_f(mx)) {                                   // normalize_logits fallback :136-141
-            for (int i = lane; i < n + 1; i += 64) pr[i] = 1.0f / (float)(n + 1);
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-        for (int i = lane; i < n + 1; i += 64) { const float lg = pr[i]; pr[i] = finite_f(lg) ? hm_expf(lg - mx) : 0.0f; }
-        __builtin_amdgcn_wave_barrier();
-        double sum = 0.0;                                      // index-order double sum, as the reference
-        for (int i = 0; i < n + 1; ++i) sum += (double)pr[i];
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < n + 1; i += 64) pr[i] = (float)((double)pr[i] / sum);
-        __builtin_amdgcn_wave_barrier();
-    }
-    PROF_ADD_T(40, te2, 64);
-    // root Dirichlet noise (node.h:286-315): gamma draws were made on the host
-    Node leaf = s.nodes[ctx.leaf];
-    if (leaf.depth == 0 && s.g->alpha > 0.0f && s.g->eps > 0.0f) {
-        for (int b = 0; b < 2; ++b) {
-            const int n = nAct[b];
-            if (n <= 1) continue;
-            float* pr = L.priors[b];
-            const float* nz = s.noise[b];
-            float total = 0.0f;
-            for (int i = 0; i < n && i < NOISE_CAP; ++i) total += nz[i];
-            if (total <= 0.0f) continue;
-            const float eps = clampf(s.g->eps, 0.0f, 1.0f);
-            for (int i = lane; i < n; i += 64) pr[i] = (1.0f - eps) * pr[i] + eps * nz[i < NOISE_CAP ? i : NOISE_CAP - 1] / total;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
     // JointCandidateGenerator::initialize (joint_action.h:195-278): rank sort by (prior desc, index asc)
     // one bump allocation for the header, both sorted move / prior arrays, the frontier, the visited list and the first four
     // edge slots (seven round trips to the game's arena counter otherwise)
+    int nAct[2] = {nReal[0] + 1, nReal[1] + 1};
     auto units = [](u32 bytes) { return (bytes + 7) >> 3; };
     const u32 uHdr = units(sizeof(GenHdr)), uA = units((u32)nAct[0] * 4), uB = units((u32)nAct[1] * 4);
     const u32 uHeap = units(16 * 8), uVis = units(32 * 4), uEdges = units(4 * sizeof(Edge));
@@ -1111,29 +1029,35 @@ __device__ inline void expand_leaf(G& s, const RulesTab& rt, ExpLds& L, const Ct
     h.heapCap = 16; h.heapSize = 0; h.heap = offP[1] + uB;
     h.visCap = 32; h.visSize = 0; h.visited = h.heap + uHeap;
     const u32 firstEdges = h.visited + uVis;
-    PROF_T(te3);
-    for (int b = 0; b < 2; ++b) {
-        const int n = nAct[b];
-        const u32* list = L.lists[b];
-        const float* pr = L.priors[b];
-        u32* outM = reinterpret_cast<u32*>(s.arena + offM[b]);
-        float* outP = reinterpret_cast<float*>(s.arena + offP[b]);
-        for (int i = lane; i < n; i += 64) {
-            const float pi = pr[i];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) { const float pj = pr[j]; rank += (pj > pi) || (pj == pi && j < i); }
-            const u32 m = list[i];
-            const u32 cap = (m != 0 && (b ? is_capture(bd[1], m) : is_capture(bd[0], m))) ? 0x80000000u : 0u;
-            outM[rank] = m | cap;
-            outP[rank] = pi;
+    // root Dirichlet noise (node.h:286-315) applies to the root's own expansion only
+    const Node leaf0 = s.nodes[ctx.leaf];
+    const bool noisy = leaf0.depth == 0 && s.g->alpha > 0.0f && s.g->eps > 0.0f;
+    if (pre) {
+        // the persistent evaluator ran the prior pipeline on the logits in its LDS (hm_policy.hpp) and left the sorted arrays
+        const u32* sm = pre->moves + ((size_t)buf * BATCH + row) * 2 * HM_MAX_MOVES;
+        const float* spr = pre->priors + ((size_t)buf * BATCH + row) * 2 * HM_MAX_MOVES;
+        for (int b = 0; b < 2; ++b) {
+            u32* outM = reinterpret_cast<u32*>(s.arena + offM[b]);
+            float* outP = reinterpret_cast<float*>(s.arena + offP[b]);
+            for (int i = lane; i < nAct[b]; i += 64) { outM[i] = sm[(size_t)b * HM_MAX_MOVES + i]; outP[i] = spr[(size_t)b * HM_MAX_MOVES + i]; }
+        }
+    } else {
+        for (int b = 0; b < 2; ++b) {
+            const uint16_t* pol = b == 0 ? piA : piB;
+            board_priors_sorted(L.lists[b], L.priors[b], nReal[b], (int)(b ? bd[1].stm : bd[0].stm), s.pl->polNormal, s.pl->polDrop,
+                                [pol](int idx) { return pol[idx]; }, noisy ? s.noise[b] : nullptr, s.g->eps,
+                                reinterpret_cast<u32*>(s.arena + offM[b]), reinterpret_cast<float*>(s.arena + offP[b]));
         }
     }
+    PROF_ADD_T(40, te2, 64);
+    PROF_T(te3);
     wave_fence();
     PROF_ADD_T(41, te3, 64);
     PROF_T(te4);
     h.movesA = offM[0]; h.movesB = offM[1]; h.priorsA = offP[0]; h.priorsB = offP[1];
     gen_push(s, h, 0, 0);
     if (h.heapSize == 0) { gen_push(s, h, 1, 0); gen_push(s, h, 0, 1); }
+    Node leaf = leaf0;
     leaf.gen = genOff;
     leaf.expanded = 0;
     // first child (try_init_and_expand node.h:317-341)
@@ -1194,7 +1118,7 @@ __device__ inline int ctx_row(const G& s, int buf, int i) {   // inference row o
     const bool nn = lane < i && !s.ctx[buf * BATCH + lane].terminal;      // i <= BATCH: one context per lane
     return __popcll(__ballot(nn));
 }
-__device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
+__device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase, const PreSorted* pre = nullptr) {
     const Ctx& ctx = s.ctx[buf * BATCH + i];
     if (ctx.terminal) return;
     if (s.nodes[ctx.leaf].type != T_UNSOLVED) return;
@@ -1202,7 +1126,7 @@ __device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int b
     const int row = rowBase + slot;
     if (ctx.leafHash != 0) s.nodes[ctx.leaf].hash = ctx.leafHash;
     if (!(s.nodes[ctx.leaf].flags & F_EXPANDED))
-        expand_leaf(s, rt, L, ctx, buf, slot, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES);
+        expand_leaf(s, rt, L, ctx, buf, slot, rootTeam, rootAdv, out->piA + (size_t)row * HM_POLICY_VALUES, out->piB + (size_t)row * HM_POLICY_VALUES, pre);
 }
 __device__ inline void backup_batch(G& s, int buf, const NetOut* out, int rowBase) {
     const int n = s.g->ctxCount[buf];
@@ -1510,6 +1434,7 @@ __device__ inline void process_step(G& s, const RulesTab& rt, ExpLds* exp, const
 
 // Legal move lists of network leaf `slot` (both boards, lane 0 -> A, lane 1 -> B, R/B under-promotions erased as
 // utils.h:169-182) from its hm_board image: the expansion in k_process reads them instead of generating.
+template <bool WT = false>
 __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveLds& L, int g, int img, int slot, int b) {
     const int lane = threadIdx.x & 63;
     const hm_board* hb = reinterpret_cast<const hm_board*>(L.board[img]);
@@ -1528,12 +1453,24 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
             const u32 m = i < n ? list[i] : 0u;
             const bool keep = i < n && !((m & (15u << 12)) == HM_MT_PROMOTION && (((m >> 16) & 63) == HM_ROOK || ((m >> 16) & 63) == HM_BISHOP));
             const u64 km = __ballot(keep);
-            if (keep) dst[kept + __popcll(km & ((1ULL << lane) - 1ULL))] = m;
+            if (keep) {
+                // bit 31 = Position::capture(m) (JointActionCandidate's sit rules need it, joint_action.h:80-105): decided here, where
+                // the position is at hand, so that whoever sorts the priors needs only the list
+                const u32 v = m | (is_capture(p, m) ? hmp::CAPTURE_BIT : 0u);
+                u32* q = dst + kept + __popcll(km & ((1ULL << lane) - 1ULL));
+                if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the evaluator's workgroup
+                else *q = v;
+            }
             kept += __popcll(km);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) { pl.leafCounts[base + b] = kept; atomicAdd(&L.listWords, kept); }
+    if (lane == 0) {
+        const int v = kept | ((int)p.stm << 16);
+        if constexpr (WT) __hip_atomic_store(&pl.leafCounts[base + b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else pl.leafCounts[base + b] = v;
+        atomicAdd(&L.listWords, kept);
+    }
 }
 
 // The three helper waves of a game's collect phase (k_collect and the persistent k_search): classifier (wave 1), plane writer
@@ -1579,7 +1516,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
             const int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (servedB < posted) {
                 const int img = servedB & (BATCH - 1);
-                leaf_move_list(pl, s_rt, L, g, img, L.postRow[img], 1);
+                leaf_move_list<WT>(pl, s_rt, L, g, img, L.postRow[img], 1);
                 servedB++;
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
@@ -1602,7 +1539,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
             }
             const int img = served & (BATCH - 1), row = L.postRow[img];
             write_planes_f16<WT>(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
-            leaf_move_list(pl, s_rt, L, g, img, row, 0);
+            leaf_move_list<WT>(pl, s_rt, L, g, img, row, 0);
             served++;
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1758,8 +1695,8 @@ struct SearchIo {
 struct SearchCtl { int action, buf, first, ok; };
 enum : int { ACT_COLLECT = 0, ACT_FINISH = 1 };
 
-__device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L, int wave, int pending, int nctx, int rootTeam, bool rootAdv, const NetOut* out, int rowBase) {
-    for (int i = wave - 1; i < nctx; i += 3) expand_context(s, rt, L, pending, i, rootTeam, rootAdv, out, rowBase);
+__device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L, int wave, int pending, int nctx, int rootTeam, bool rootAdv, const NetOut* out, int rowBase, const PreSorted* pre) {
+    for (int i = wave - 1; i < nctx; i += 3) expand_context(s, rt, L, pending, i, rootTeam, rootAdv, out, rowBase, pre);
 }
 
 __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm, SearchIo io) {
@@ -1810,6 +1747,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     const bool rootAdv = s_game.adv != 0;
     const int rowBase = g * BATCH;
     ExpLds& myExp = wave <= 1 ? L.exp : s_exp2[wave - 2];
+    const PreSorted pre{pl.sortedMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES, pl.sortedPriors + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES};
     u64 tC = 0, tW = 0, tP = 0, nIt = 0;                            // thread 0: ticks spent collecting / waiting for the evaluator / processing
     // process of the pending batch: wait for its evaluation (unless `abortIt`), backups on wave 0 beside the expansions on waves 1..3
     auto process_pending = [&](bool abortIt) -> bool {
@@ -1845,7 +1783,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             PROF_ADD(37, tpb);
         } else if (!abortIt) {
             PROF_T(tpe);
-            expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase);
+            expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase, &pre);
             PROF_ADD_T(43, tpe, 64);
         }
         __threadfence_block();
@@ -1906,7 +1844,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             if (valid > 0) {                                        // hand the batch to the evaluator
                 unsigned items[BATCH];
                 const int net = io.netSel ? io.netSel[g] : 0;
-                for (int r = 0; r < valid; ++r) items[r] = hmq::item_pack(g, buf, r, net);
+                // the root's own expansion (first batch of a search from a fresh root) mixes Dirichlet noise into the priors
+                const bool rootRow = first && s_game.alpha > 0.0f && s_game.eps > 0.0f && !(s.nodes[s_game.root].flags & F_EXPANDED);
+                for (int r = 0; r < valid; ++r) items[r] = hmq::item_pack(g, buf, r, net) | (rootRow ? hmq::IT_ROOT : 0u);
                 s_expect[buf] += (unsigned)valid;
                 hmq::push_items(io.q, items, valid);
             }
@@ -2719,6 +2659,8 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     rc |= dalloc(sp, &pl.noise, G_ * 2 * NOISE_CAP);
     rc |= dalloc(sp, &pl.leafMoves, G_ * 2 * BATCH * 2 * HM_MAX_MOVES);
     rc |= dalloc(sp, &pl.leafCounts, G_ * 2 * BATCH * 2);
+    rc |= dalloc(sp, &pl.sortedMoves, G_ * 2 * BATCH * 2 * HM_MAX_MOVES);
+    rc |= dalloc(sp, &pl.sortedPriors, G_ * 2 * BATCH * 2 * HM_MAX_MOVES);
     if (rc) { hm_sp_destroy(sp); return rc; }
     // cpuct(N) and the PW schedule from the reference's own float expressions (search_params.h:307-317)
     // A node's visit count is bounded by the simulations of the searches its tree has lived through (tree reuse carries visits over
@@ -3037,6 +2979,8 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     a.wdl[0] = static_cast<uint16_t*>(io->wdl); a.wdl[1] = static_cast<uint16_t*>(io->wdl_2);
     a.ml[0] = static_cast<uint16_t*>(io->moves_left); a.ml[1] = static_cast<uint16_t*>(io->moves_left_2);
     a.q = q; a.done = done;
+    a.leafMoves = sp->pl.leafMoves; a.leafCounts = sp->pl.leafCounts; a.sortedMoves = sp->pl.sortedMoves; a.sortedPriors = sp->pl.sortedPriors;
+    a.polNormal = sp->pl.polNormal; a.polDrop = sp->pl.polDrop; a.noise = sp->pl.noise; a.noiseOn = (sp->alpha > 0.0f && sp->eps > 0.0f) ? 1 : 0; a.noiseEps = sp->eps;
     a.clkSum = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->sumN); a.clkCnt = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->cntN);   // the evaluator's ticks / positions
     // the evaluator first: its workgroups only ever wait for the games, never the other way round before a game has work for them
     if (int rc = hm_net_serve(net, a, consumers, sN)) return rc;
