@@ -299,7 +299,8 @@ def main():
             return res, rec, cnt
         for w in range(args.warmup):
             one_run(1000 + w)
-        tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0, lw=0)
+        tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0, lw=0,
+                   searches=0, search_kernel_ms=0.0, wait_ms=0.0, search_s=0.0, prologue_s=0.0, raw_s=0.0, seconds=0.0, positions=0)
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -308,6 +309,9 @@ def main():
             tot["iters"] += res.search_iterations; tot["collect_ms"] += res.collect_ms; tot["eval_ms"] += res.eval_ms
             tot["process_ms"] += res.process_ms; tot["nv"] += res.nodes_visited; tot["es"] += res.edges_scanned
             tot["games"] += res.games; tot["bytes"] += rec.size; tot["lw"] += res.leaf_move_words
+            tot["searches"] += res.persistent_searches; tot["search_kernel_ms"] += res.search_kernel_ms; tot["wait_ms"] += res.wait_ms
+            tot["search_s"] += res.search_seconds; tot["prologue_s"] += res.prologue_seconds; tot["raw_s"] += res.raw_seconds
+            tot["seconds"] += res.seconds; tot["positions"] += res.searched_positions
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         samples = sum_over_ranks(tot["samples"])
@@ -345,7 +349,9 @@ def main():
         extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
                              "lockstep_iterations": tot["iters"], "leg_ms_per_iteration": legs,
-                             "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9}
+                             "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9,
+                             "persistent_searches": tot["searches"], "search_kernel_ms_total": tot["search_kernel_ms"], "wait_ms_total": tot["wait_ms"],
+                             "wall_split_s": {"run": tot["seconds"], "search": tot["search_s"], "prologue": tot["prologue_s"], "raw_policy": tot["raw_s"]}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_selfplay_baseline(model, args.nodes)
         line = dict(metric="self-play positions/sec @ nodes=400", value=samples / dt, unit="positions/s", steps=args.steps,
