@@ -112,7 +112,10 @@ __device__ __forceinline__ bool wait_count(SrvQueue* q, unsigned* counter, unsig
         __builtin_amdgcn_s_sleep(4);
         if ((spins & 255u) == 255u) {
             if (__hip_atomic_load(&q->error, HMQ_RLX)) return false;
-            if (spin_expired(t0)) { __hip_atomic_store(&q->error, 3u, HMQ_RLX); return false; }
+            const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
+            // no evaluator workgroup has started in all that time: the two kernels are being run one after the other
+            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(&q->consIn, HMQ_RLX) == 0u) { __hip_atomic_store(&q->error, 4u, HMQ_RLX); return false; }
+            if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(&q->error, 3u, HMQ_RLX); return false; }
         }
     }
 }

@@ -938,6 +938,7 @@ struct WaveLds {
     int posted, done;        // hand-off flags (k_collect: wave 0 posts images, wave 1 writes their planes)
     int postBuf;             // which of the two batches (0/1) the posted leaves belong to
     int postRow[BATCH];      // plane row of each posted image (ring slot = post number & 7)
+    int postReady[BATCH];    // persistent search: arrivals for each posted image (+1 plane writer, +1 generator, +4 / +8 classifier: network leaf / dropped)
     int servedCnt;           // posts the plane-writer wave has finished (flow control of the image ring)
     int servedCntB;          // posts whose board-B move list the generator wave has finished
     int postCount;           // images posted so far in this launch (classifier wave's counter)
@@ -1186,7 +1187,26 @@ __device__ inline void abort_batch(G& s, int buf) {   // searchthread.cc:641-659
 // traversal never reads the Node of a leaf whose request is outstanding (svc_wait guards in scan_edges / select_and_expand /
 // canonicalize_child), one request is in flight at a time, and requests are served in order, so context slots and plane rows
 // are assigned exactly as the single-threaded loop assigns them.
-__device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv, int seq) {
+// Persistent search: a posted leaf image is handed to the evaluator the moment its plane row, both move lists and the classifier's
+// verdict ("a network leaf") are there — by whichever of the three waves arrives last — instead of at the end of the collect phase:
+// the evaluation of the first leaves of a batch then runs beside the descents that find the last ones.  Every writer has drained its
+// write-through stores (s_waitcnt vmcnt(0)) before it arrives, and the arrivals are LDS atomics, so the item follows all its bytes.
+struct PubCtx { hmq::SrvQueue* q; unsigned itemBase; unsigned* expect; };
+__device__ __forceinline__ void post_arrive(WaveLds& L, const PubCtx* pc, int post, int inc) {
+    if ((threadIdx.x & 63) != 0) return;
+    const int slot = post & (BATCH - 1);
+    const int now = atomicAdd(&L.postReady[slot], inc) + inc;
+    if ((now & 3) != 2 || !(now & 12)) return;
+    __hip_atomic_store(&L.postReady[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (now & 4) {
+        const unsigned item = pc->itemBase | ((unsigned)L.postRow[slot] << 21);
+        atomicAdd(pc->expect, 1u);
+        hmq::push_items(pc->q, &item, 1);
+    }
+}
+
+template <bool WT = false>
+__device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv, int seq, const PubCtx* pc = nullptr) {
     const int lane = threadIdx.x & 63;
     const WaveLds::Req rq = L.req[seq & 1];
     const TrajEnt* trajReq = L.trajReq[seq & 1];
@@ -1208,8 +1228,10 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     // The plane-writer wave starts on this leaf now, into row `valid`, while the terminal test below runs: a leaf that turns out
     // terminal (or is dropped) simply leaves `valid` where it is and the next network leaf overwrites the row (posts are served
     // in order).  Everything the planes and the move lists need is known here.
+    int myPost = -1;
     if (reserved) {
         const int np_ = L.postCount;
+        myPost = np_;
         while (np_ - min(__hip_atomic_load(&L.servedCnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP),
                          __hip_atomic_load(&L.servedCntB, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= BATCH) __builtin_amdgcn_s_sleep(1);   // ring slot free
         hm_board* hb = reinterpret_cast<hm_board*>(L.board[np_ & (BATCH - 1)]);
@@ -1246,6 +1268,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     if (lane == 0) L.reqResult = result;
     wave_fence();
     if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (WT) { if (myPost >= 0) post_arrive(L, pc, myPost, result == 0 ? 4 : 8); }
     PROF_ADD_T(24, tsv, 64);
     if (result == 0) {
         const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
@@ -1476,7 +1499,7 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
 // The three helper waves of a game's collect phase (k_collect and the persistent k_search): classifier (wave 1), plane writer
 // (wave 2), generator (wave 3).  Each returns once the traversal wave has raised svcStop and every request has been served.
 template <bool WT = false>
-__device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, WaveLds& L, const Pools& pl, const Game& s_game, int g, uint16_t* planesNext, int wave) {
+__device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, WaveLds& L, const Pools& pl, const Game& s_game, int g, uint16_t* planesNext, int wave, const PubCtx* pc = nullptr) {
     if (wave == 1) {
         // classifier: serves the traversal's leaf requests in order; ends once the traversal has stopped and every request is served
         const int rootTeam = s_game.team;
@@ -1490,7 +1513,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 if (rs == seen) break;
             }
             seen++;                                                // requests are served one by one, in order
-            serve_leaf(s, s_rt, L, rootTeam, rootAdv, seen);
+            serve_leaf<WT>(s, s_rt, L, rootTeam, rootAdv, seen, pc);
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1517,6 +1540,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
             if (servedB < posted) {
                 const int img = servedB & (BATCH - 1);
                 leaf_move_list<WT>(pl, s_rt, L, g, img, L.postRow[img], 1);
+                if constexpr (WT) { hmq::drain_stores(); post_arrive(L, pc, servedB, 1); }
                 servedB++;
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
@@ -1540,6 +1564,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
             const int img = served & (BATCH - 1), row = L.postRow[img];
             write_planes_f16<WT>(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
             leaf_move_list<WT>(pl, s_rt, L, g, img, row, 0);
+            if constexpr (WT) { hmq::drain_stores(); post_arrive(L, pc, served, 1); }
             served++;
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1710,6 +1735,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
     __shared__ SearchCtl s_ctl;
     __shared__ unsigned s_expect[2];                                // rows published per buffer so far
+    __shared__ PubCtx s_pub;
     const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     PROF_INIT();
     G s = make_view(pl, prm, g);
@@ -1804,6 +1830,12 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             // hand-off state of one collect phase
             L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0;
             L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
+            for (int i = 0; i < BATCH; ++i) L.postReady[i] = 0;
+            // the root's own expansion (first batch of a search from a fresh root) mixes Dirichlet noise into the priors
+            const bool rootRow = first && s_game.alpha > 0.0f && s_game.eps > 0.0f && !(s.nodes[s_game.root].flags & F_EXPANDED);
+            const int bufNow = first ? 0 : 1 - s_game.pending;
+            s_pub.q = io.q; s_pub.expect = &s_expect[bufNow];
+            s_pub.itemBase = hmq::item_pack(g, bufNow, 0, io.netSel ? io.netSel[g] : 0) | (rootRow ? hmq::IT_ROOT : 0u);
         }
         __syncthreads();
         PROF_ADD(38, tct);
@@ -1831,7 +1863,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0;
             collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
             if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave);
+        } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave, &s_pub);
         PROF_ADD(33, tcp);
         PROF_T(tcd);
         hmq::drain_stores();                                        // the write-through stores of this batch's plane rows have left every wave
@@ -1839,17 +1871,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         PROF_ADD(39, tcd);
         PROF_ADD(32, tcp);
         PROF_T(tpu);
-        if (threadIdx.x == 0) {
-            const int valid = s_game.validCount[buf];
-            if (valid > 0) {                                        // hand the batch to the evaluator
-                unsigned items[BATCH];
-                const int net = io.netSel ? io.netSel[g] : 0;
-                // the root's own expansion (first batch of a search from a fresh root) mixes Dirichlet noise into the priors
-                const bool rootRow = first && s_game.alpha > 0.0f && s_game.eps > 0.0f && !(s.nodes[s_game.root].flags & F_EXPANDED);
-                for (int r = 0; r < valid; ++r) items[r] = hmq::item_pack(g, buf, r, net) | (rootRow ? hmq::IT_ROOT : 0u);
-                s_expect[buf] += (unsigned)valid;
-                hmq::push_items(io.q, items, valid);
-            }
+        if (threadIdx.x == 0) {                                     // (the batch's rows went to the evaluator one by one: post_arrive)
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
             tC += t1 - t0; nIt++;
         }
@@ -1900,6 +1922,23 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         hmq::producer_exit(io.q);
     }
     PROF_FLUSH();
+}
+
+// Holds the evaluator's stream until every search workgroup has started (k_search is launched first, on the other stream): the
+// games then own their CUs before the evaluator kernel takes ALL the others.  Evaluator workgroups that find no CU simply wait in the
+// dispatcher until games end (each gets its poison item then); the reverse order could leave a game workgroup waiting for a CU that
+// only evaluator workgroups waiting for that game could vacate.
+__global__ void k_wait_trees(hmq::SrvQueue* q, unsigned trees) {
+    if (threadIdx.x != 0) return;
+    const hmq::u64q t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(&q->treesIn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= trees) return;
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(&q->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            if ((hmq::u64q)__builtin_amdgcn_s_memrealtime() - t0 > hmq::MEET_LIMIT_TICKS) { __hip_atomic_store(&q->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        }
+    }
 }
 
 // Final move rule of Agent::run_search (agent.cc:859-889): Node::get_best_move_idx_with_q_weight (node.h:656-754,
@@ -2541,6 +2580,7 @@ struct hm_sp {
     hipStream_t sTree = nullptr, sNet = nullptr;   // queues of their own for the two persistent kernels
     unsigned lastQueueError = 0;           // SrvQueue::error of the last hm_sp_search (4: the two kernels did not run together)
     bool lastBeginMasked = false;          // hm_sp_begin_search was given a mask (hm_sp_begin_again relaunches with the same inputs)
+    int lastBeginActive = 0;               // slots that mask admitted (an upper bound of the searching game workgroups)
     unsigned* h_qinit = nullptr;           // pinned: {producers, error, consumers} as uploaded after the memset
     // Per-ply traffic with the host goes through two pinned staging blocks and contiguous device blocks: one copy per call
     // and direction instead of one per array (a pageable hipMemcpy costs tens of microseconds before the first byte moves).
@@ -2874,6 +2914,8 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
     }
     sp->alpha = alpha; sp->eps = eps;
     sp->lastBeginMasked = mask != nullptr;
+    sp->lastBeginActive = G_;
+    if (mask) { int n = 0; for (int g = 0; g < G_; ++g) n += mask[g] ? 1 : 0; sp->lastBeginActive = n; }
     return 0;
 }
 // The prologue of the last hm_sp_begin_search once more, from the inputs still on the device (targets, seeds, mask, noise draws):
@@ -2918,16 +2960,11 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
 // which the queue protocol relies on only for speed, the spins being bounded — when their number does not exceed the CU count.
 int hm_sp_search_consumers(const hm_sp* sp) {
     if (!sp || sp->numCUs <= 0) return 0;
-    // Workgroups are dealt round-robin over the XCDs and, inside an XCD, over its shader engines, IN ORDER: a workgroup whose
-    // engine has no free CU waits there — and holds up every workgroup behind it — even while other engines have room (observed:
-    // with one CU per XCD left free, a game workgroup waited until the evaluator kernel gave up).  So the evaluator takes the same
-    // number of CUs in every shader engine (8 XCDs x 4 engines of 8 CUs on MI355X) and leaves each engine room for its share of the
-    // game workgroups plus one.
-    const int engines = 32, perEngine = sp->numCUs / engines;
-    if (perEngine < 2) return 0;
-    const int gamesPerXcd = (sp->nGames + 7) / 8, gamesPerEngine = (gamesPerXcd + 3) / 4;
-    const int n = (perEngine - gamesPerEngine - 1) * engines;
-    return n >= 8 ? n : 0;
+    // every CU the game workgroups leave: a workgroup of either kernel takes a whole CU (the search kernel the full register file,
+    // the evaluator most of it), the games are placed first (k_wait_trees), and an evaluator workgroup that finds no CU only waits
+    const int slots = sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames;
+    const int n = sp->numCUs - std::min(slots, sp->nGames);
+    return (sp->numCUs - sp->nGames) >= 8 && n >= 8 ? n : 0;
 }
 
 // The whole node-budget search of every slot hm_sp_begin_search left in the searching state, with the native evaluator: two
@@ -2982,8 +3019,7 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     a.leafMoves = sp->pl.leafMoves; a.leafCounts = sp->pl.leafCounts; a.sortedMoves = sp->pl.sortedMoves; a.sortedPriors = sp->pl.sortedPriors;
     a.polNormal = sp->pl.polNormal; a.polDrop = sp->pl.polDrop; a.noise = sp->pl.noise; a.noiseOn = (sp->alpha > 0.0f && sp->eps > 0.0f) ? 1 : 0; a.noiseEps = sp->eps;
     a.clkSum = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->sumN); a.clkCnt = reinterpret_cast<hmq::u64q*>(&sp->pl.clk->cntN);   // the evaluator's ticks / positions
-    // the evaluator first: its workgroups only ever wait for the games, never the other way round before a game has work for them
-    if (int rc = hm_net_serve(net, a, consumers, sN)) return rc;
+    // the games first: they take their CUs and start collecting; the evaluator's stream waits for all of them to be in (k_wait_trees)
     SearchIo sio;
     sio.planes[0] = static_cast<uint16_t*>(io->planes[0]); sio.planes[1] = static_cast<uint16_t*>(io->planes[1]);
     for (int b = 0; b < 2; ++b) sio.out[b] = NetOut{a.value[b], a.piA[b], a.piB[b], a.wdl[b], a.ml[b]};
@@ -2992,12 +3028,16 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
     const hipError_t le = hipGetLastError();
     (void)hipEventRecord(sp->evT1, sT);
-    if (le != hipSuccess) {
-        // the evaluator workgroups are waiting for games that never come: release them
+    if (le != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("k_search launch failed: ") + hipGetErrorString(le));
+    hipLaunchKernelGGL(k_wait_trees, dim3(1), dim3(64), 0, sN, q, (unsigned)sp->nGames);
+    int rcServe = hipGetLastError() == hipSuccess ? 0 : hm_fail(HM_ERR_NO_DEVICE, "k_wait_trees launch failed");
+    if (!rcServe) rcServe = hm_net_serve(net, a, consumers, sN);
+    if (rcServe) {
+        // the game workgroups are waiting for an evaluator that never comes: release them
         sp->h_qinit[4] = 1u;
-        (void)hipMemcpyAsync(&q->error, &sp->h_qinit[4], 4, hipMemcpyHostToDevice, sT);
+        (void)hipMemcpyAsync(&q->error, &sp->h_qinit[4], 4, hipMemcpyHostToDevice, sN);
         (void)hipStreamSynchronize(sT); (void)hipStreamSynchronize(sN);
-        return hm_fail(HM_ERR_NO_DEVICE, std::string("k_search launch failed: ") + hipGetErrorString(le));
+        return rcServe;
     }
     HIPCHK(hipStreamSynchronize(sT));
     HIPCHK(hipStreamSynchronize(sN));
