@@ -626,6 +626,7 @@ __device__ __forceinline__ void depthwise_rows_ld(const h16* y1, h16* y2, int ld
 // evaluator rise_serve): input row `pin`, outputs to row `sIdx` of the head tensors.
 #define HM_STAMP() do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0 && dbgN < 256) dbg[dbgN++] = __builtin_amdgcn_s_memtime(); } while (0)
 // WT: the heads are written with write-through stores (hm_queue.hpp), the policy planes staged through LDS into 16-byte chunks.
+constexpr int PRIOR_SCRATCH_HALFS = 2 * (HM_MAX_MOVES * 4 + (HM_MAX_MOVES + 8) * 4 + HM_MAX_MOVES * 4 + HM_MAX_MOVES * 4) / 2;   // PriorEpi's LDS, in halfs
 // PolicyEpi (WT only): called by every thread with the staged logits `pol` ([160][64] fp16 in LDS: board A's 73 planes, then board
 // B's) and `scratch` (the LDS behind them) in place of storing the logits; it ends with a workgroup barrier of its own.
 struct NoPolicyEpi { static constexpr bool present = false; __device__ void operator()(const h16*, unsigned char*) const {} };
@@ -647,7 +648,10 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
     float* Pf = reinterpret_cast<float*>(U + uHalfs);                   // per-chunk parameters: b1[chunk], b2[chunk], b3[C]  (uHalfs % 8 == 0)
     h16* Pdw = reinterpret_cast<h16*>(Pf + 2 * copMax + C);             // depthwise weights [chunk][k*k]
     float* Ev = reinterpret_cast<float*>(Pdw + (((size_t)copMax * 25 + 7) & ~(size_t)7));   // ECA / head scratch: [4][C] + [C] + 64
-    h16* Pol = U + ((65 * (ldx > 88 ? ldx : 88) + 7) & ~7);             // WT: policy staging [160][64] behind Ss (host checks that U holds it)
+    // WT: policy staging [160][64] (+ the prior pipeline's scratch) behind Ss inside the union region when it has the room (narrow
+    // trunks: their expansions are wide against C), else in Xs, which is dead once the policy trunk has been computed (C = 384)
+    constexpr int polOff = (65 * (ldx > 88 ? ldx : 88) + 7) & ~7;
+    h16* Pol = polOff + 160 * 64 + PRIOR_SCRATCH_HALFS <= uHalfs ? U + polOff : Xs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = 8 * (lane >> 5);
     const int stile = wave & 1;                                         // the square half of every tile this wave computes
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(512, 1) void rise_forward_narrow(const NetDesc* __r
 // The prior pipeline of an evaluated leaf (hm_policy.hpp) on the logits still in LDS: wave 0 serves board A, wave 1 board B — legal
 // moves in from the search workgroup's list, moves and priors in prior order out (write-through, 16 bytes per lane) to the arrays
 // the search workgroup copies into its tree.  The 18.7 KB of logits per position are never written to HBM.
-constexpr int PRIOR_SCRATCH_BYTES = 2 * (HM_MAX_MOVES * 4 + (HM_MAX_MOVES + 8) * 4 + HM_MAX_MOVES * 4 + HM_MAX_MOVES * 4);
+constexpr int PRIOR_SCRATCH_BYTES = 2 * PRIOR_SCRATCH_HALFS;
 struct PriorEpi {
     static constexpr bool present = true;
     const hmq::ServeArgs* a;
@@ -1075,9 +1079,9 @@ static hipError_t with_narrow(const hm_net* net, F f) {
 }
 int hm_net_can_serve(const hm_net* net) {
     if (!net || !net->narrow) return 0;
-    const int ldx = net->nd.C + 8;
-    const int polOff = (65 * std::max(ldx, 88) + 7) & ~7;            // narrow_position's Pol: behind Ss inside the union region
-    return polOff + 160 * 64 + hmn::PRIOR_SCRATCH_BYTES / 2 <= net->uHalfs ? 1 : 0;     // + the prior pipeline's scratch (PriorEpi)
+    // narrow_position's policy staging + prior scratch: inside the union region behind Ss, or else in Xs
+    const int ldx = net->nd.C + 8, polOff = (65 * std::max(ldx, 88) + 7) & ~7, need = 160 * 64 + hmn::PRIOR_SCRATCH_HALFS;
+    return (polOff + need <= net->uHalfs || need <= 65 * ldx) ? 1 : 0;
 }
 int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t st) {
     using namespace hmn;
