@@ -197,6 +197,28 @@ int ora_search_pv_lines(void* sp, int multi_pv, int max_depth, int* out_idx, int
 void ora_search_set_tree_reuse(void* sp, int on) { Search* s = static_cast<Search*>(sp); s->enableTreeReuse = on != 0; if (!on) s->reset_search_state(); }
 void ora_search_reset(void* sp) { static_cast<Search*>(sp)->reset_search_state(); }
 int ora_search_reused_visits(void* sp) { return static_cast<Search*>(sp)->reusedVisits; }
+// the candidates Agent::store_next_root_candidates kept after the last run (agent.cc:1373-1451): [0] = the selected child, then every
+// reply generated below it.  out[i*6..]: joint move A, B of the reply (0, 0 for the selected child), visits, node type, endInPly, is it the
+// selected child's own best move
+int ora_search_retained(void* sp, int* out, int cap) {
+    Search* s = static_cast<Search*>(sp);
+    const auto& c = s->nextRootCandidates;
+    if (c.empty() || !c[0].node) return 0;
+    const std::shared_ptr<Node>& own = c[0].node;
+    const int best = own->isExpanded && !own->children.empty() ? own->get_best_move_idx_with_q_weight(s->cfg.qVetoDelta, s->cfg.qValueWeight) : -1;
+    int n = 0;
+    for (size_t i = 0; i < c.size() && n < cap; ++i, ++n) {
+        int* o = out + n * 6;
+        o[0] = o[1] = 0; o[5] = 0;
+        if (i > 0) {
+            size_t k = 0, seen = 0;                      // the (i-1)-th non-null child of the selected child
+            for (; k < own->children.size(); ++k) if (own->children[k] && seen++ == i - 1) break;
+            o[0] = (int)own->gen.generated[k].moveA; o[1] = (int)own->gen.generated[k].moveB; o[5] = (int)k == best ? 1 : 0;
+        }
+        o[2] = c[i].node ? c[i].node->visits : -1; o[3] = c[i].node ? (int)c[i].node->nodeType : -1; o[4] = c[i].node ? c[i].node->endInPly : 0;
+    }
+    return n;
+}
 void ora_search_info(void* sp, int* out /*8*/) {
     Search* s = static_cast<Search*>(sp);
     out[0] = s->nodesSearched; out[1] = s->evalRows; out[2] = s->evalCalls; out[3] = s->sameBatchCollisions;

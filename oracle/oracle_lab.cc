@@ -190,6 +190,14 @@ int ora_lab_select_and_expand(void* h, void* board, int rootAdv, int* reserved, 
     if (trajLen) *trajLen = (int)l.search.trajectory.size();
     return l.id_of(s.leaf);
 }
+// Agent::store_next_root_candidates / try_reuse_tree (agent.cc:1345-1451) on the lab's root and board
+void ora_lab_store_candidates(void* h, void* board, int adv) { L(h).search.store_next_root_candidates(*static_cast<Board*>(board), adv != 0); }
+int ora_lab_retained_count(void* h) { return (int)L(h).search.nextRootCandidates.size(); }
+int ora_lab_try_reuse(void* h, void* board, int adv, int team) {
+    Lab& l = L(h);
+    Board& b = *static_cast<Board*>(board);
+    return l.id_of(l.search.try_reuse_tree(b.hash_key(adv != 0), team, Search::board_signature(b)));
+}
 // shape_value (searchthread.cc:569-619) on f32 heads rounded to fp16 like the engine's outputs
 float ora_lab_shape_value(void* h, float value, const float* wdl, float movesLeft) {
     uint16_t w[3] = {0, 0, 0};

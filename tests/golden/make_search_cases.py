@@ -299,13 +299,34 @@ CASES = [
         dict(op="unmake_moves", board="board"),
         dict(op="expect_board", board="board", what="last_move", which=0, eq=0),
         dict(op="planes", board="board", team=W, adv=False, zero_planes=[32, 33])]),
+    # Tree reuse between searches (Agent::store_next_root_candidates / try_reuse_tree, agent.cc:1345-1451): the selected child AND
+    # every reply generated below it are retained (3 candidates here); the non-principal reply is adopted with its solver state.
+    dict(test="EngineTest.TreeReuseRetainsNonPrincipalOpponentReplies", ref="test_move_gen.cc:1332-1391", gpu="tree_reuse", steps=[
+        dict(op="board", **{"as": "board"}),
+        dict(op="expect_board", board="board", what="hash_key", adv=False, **{"as": "rootHash"}),
+        node("root", W, hash="rootHash"),
+        init("root", board="board", a=[{"uci": [0, "e2e4"]}], b=[0], pa=[1.0], pb=[1.0], adv=False, a_on=True, b_on=False),
+        expect("n_children", "root", eq=1), child("root", 0, "opp"),
+        dict(op="board", **{"as": "after"}), dict(op="make_moves", board="after", a={"uci": [0, "e2e4"]}, b=0),
+        init("opp", board="after", a=[{"uci": [0, "e7e5"]}, {"uci": [0, "c7c5"]}], b=[0], pa=[0.75, 0.25], pb=[1.0], adv=True, a_on=True, b_on=True),
+        dict(op="expand_next", node="opp", reserve=False, expect_non_null=True, expect_idx=1),
+        expect("n_children", "opp", eq=2), child("opp", 0, "r0"), child("opp", 1, "r1"),
+        call("mark", "r0", type=WIN, ply=5), call("mark", "r1", type=WIN, ply=3),
+        dict(op="set_root", node="root"),
+        dict(op="store_candidates", board="board", adv=False, expect_retained=3),
+        dict(op="joint_make", node="opp", idx=1, board="after"),                  # the position actually reached: the non-principal reply
+        dict(op="try_reuse", board="after", adv=False, team=W, expect="r1", **{"as": "reused"}),
+        expect("type", "reused", eq=WIN), expect("end_in_ply", "reused", eq=3)]),
 ]
 
 # reference TESTs in the same file that are NOT restated here, with the reason (printed so the run documents itself)
 SKIPPED = {
-    "SearchParamsTest.EarlyStoppingRequiresFactoredVisitLead": "time-managed search (out of scope: self-play uses node budgets)",
-    "PonderModeTest.*": "pondering (out of scope)",
-    "EngineTest.TreeReuseRetainsNonPrincipalOpponentReplies": "tree reuse (out of scope: self-play resets the search every move, selfplay.cc:653)",
+    "SearchParamsTest.EarlyStoppingRequiresFactoredVisitLead": "a host-side rule of the time-managed search: restated as a known-answer test of hm_insurmountable_visit_lead "
+                                                               "(tests/test_uci_time.py::test_reference_known_answer_visit_lead)",
+    "PonderModeTest.SearchInfoResetStartTime / SearchOptionsPonderFlags / AgentPonderHitTransitions (:1304-1330)":
+        "SearchInfo / SearchOptions / Agent are host objects of the UCI layer with no counterpart class here; the behaviour they assert — the clock restarts "
+        "at ponderhit, `go ponder` searches silently while an ordinary `go` does not ponder, ponderhit on an idle engine is a safe no-op — is asserted on the "
+        "product through the UCI front end (tests/test_gpu_uci.py::test_reference_ponder_mode_cases, ::test_go_ponder_runs_until_ponderhit_or_stop)",
     "EngineTest.SettingCurrentFenClearsSearchHistory / board + movegen tests (:127-143, :328-444, :1393-1571, :1573-1593, :1692-1811)":
         "Board/movegen behaviour pinned bit for bit against the reference build itself (oracle/difftest.cc, tests/golden/ref_playout.npz, scenarios.json)",
     "JointActionTest.* (:159-278), planes (:68-157)": "already restated in tests/test_oracle_search.py and tests/test_oracle_golden.py",

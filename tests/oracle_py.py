@@ -186,6 +186,7 @@ lib.ora_fen.restype, lib.ora_fen.argtypes = _i, [_vp, _i, C.c_char_p, _i]
 lib.ora_search_set_tree_reuse.restype, lib.ora_search_set_tree_reuse.argtypes = None, [_vp, _i]
 lib.ora_search_reset.restype, lib.ora_search_reset.argtypes = None, [_vp]
 lib.ora_search_reused_visits.restype, lib.ora_search_reused_visits.argtypes = _i, [_vp]
+lib.ora_search_retained.restype, lib.ora_search_retained.argtypes = _i, [_vp, _vp, _i]
 lib.ora_search_trace.restype, lib.ora_search_trace.argtypes = _i, [_vp, _vp, _i]
 lib.ora_classify.restype, lib.ora_classify.argtypes = _i, [_vp, _i, _i, _i, _i]
 lib.ora_search_ctx_trace.restype, lib.ora_search_ctx_trace.argtypes = _i, [_vp, _vp, _i]
@@ -214,6 +215,12 @@ class Search:
     def set_tree_reuse(self, on=True): lib.ora_search_set_tree_reuse(self.h, int(on))      # ENABLE_TREE_REUSE between run() calls (the UCI front end)
     def reset(self): lib.ora_search_reset(self.h)                                           # Agent::reset_search_state
     def reused_visits(self): return int(lib.ora_search_reused_visits(self.h))               # -1 = fresh root
+
+    def retained(self):
+        """next-root candidates kept after the last run: rows (move_a, move_b, visits, type, end_in_ply, is_principal_reply); row 0 = the selected child"""
+        out = np.zeros((512, 6), np.int32)
+        n = lib.ora_search_retained(self.h, out.ctypes.data, 512)
+        return out[:n]
 
     def set_evaluator(self, fn):
         """fn(planes uint16 [n,4736]) -> (value[n], piA[n,4672], piB[n,4672], wdl[n,3], ml[n]) uint16 arrays."""

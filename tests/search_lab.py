@@ -30,6 +30,7 @@ for name, res, args in [
     ("ora_lab_backup", None, [_vp, _vp, _vp, _i, _f]), ("ora_lab_cancel_vl", None, [_vp, _vp, _vp, _i]),
     ("ora_lab_best_move", _i, [_vp, _i, _f, _f]), ("ora_lab_get", _d, [_vp, _i, _i, _i]), ("ora_lab_set_root", None, [_vp, _i]),
     ("ora_lab_tt_insert_or_get", _i, [_vp, _u64, _i]), ("ora_lab_tt_hits", _i, [_vp]),
+    ("ora_lab_store_candidates", None, [_vp, _vp, _i]), ("ora_lab_retained_count", _i, [_vp]), ("ora_lab_try_reuse", _i, [_vp, _vp, _i, _i]),
     ("ora_lab_select_and_expand", _i, [_vp, _vp, _i, _P(_i), _P(_i), _P(_i)]), ("ora_lab_shape_value", _f, [_vp, _f, _vp, _f]),
     ("ora_normalize_logits", None, [_vp, _i, _i, _vp]), ("ora_normalized_probability", None, [_vp, _i, _vp, _i, _i, _i, _vp]),
     ("ora_is_policy_move_representable", _i, [_u32]), ("ora_policy_index_of_label", _i, [C.c_char_p]), ("ora_f32_to_f16", C.c_uint16, [_f]),
@@ -234,6 +235,19 @@ class Runner:
                 assert bool(res.value) == s["expect_reserved"], s
             if "expect_pending" in s:
                 assert pend.value == (self.nid(s["expect_pending"]) if s["expect_pending"] else -1), (s, pend.value)
+        elif op == "store_candidates":          # Agent::store_next_root_candidates (agent.cc:1373-1451) on the lab's root
+            L.ora_lab_store_candidates(h, self.boards[s["board"]].h, int(s["adv"]))
+            if "expect_retained" in s:
+                assert L.ora_lab_retained_count(h) == s["expect_retained"], (s, L.ora_lab_retained_count(h))
+        elif op == "try_reuse":                 # Agent::try_reuse_tree (agent.cc:1345-1371) for the position on `board`
+            got = L.ora_lab_try_reuse(h, self.boards[s["board"]].h, int(s["adv"]), s["team"])
+            assert got == (self.nid(s["expect"]) if s["expect"] else -1), (s, got)
+            if s.get("as") and got >= 0:
+                self.nodes[s["as"]] = got
+        elif op == "joint_make":                # Board::make_moves of joint action idx of `node`, kept on the board
+            ma, mb, fa, fb = _u32(0), _u32(0), _f(0), _f(0)
+            L.ora_lab_joint_action(h, self.nid(s["node"]), s["idx"], ma, mb, fa, fb)
+            assert self.boards[s["board"]].make_moves(ma.value, mb.value) == 0
         elif op == "peek_make_hash" or op == "action_make_hash":
             ma, mb = _u32(0), _u32(0)
             if op == "peek_make_hash":
@@ -308,8 +322,11 @@ class Runner:
                 got = s["eq"] if L.ora_board_last_move(bd.h, s["which"]) == self.last_made[s["board"]][s["which"]] != 0 else None
             else:
                 raise KeyError(w)
-            want = self.vars[s["eq_var"]] if "eq_var" in s else s["eq"]
-            assert got == want, (s, got)
+            if "as" in s:                       # remember the value (e.g. a hash key for a node) instead of comparing it
+                self.vars[s["as"]] = got
+            else:
+                want = self.vars[s["eq_var"]] if "eq_var" in s else s["eq"]
+                assert got == want, (s, got)
         elif op == "classify":
             bd = self.boards[s["board"]]
             r = self.classify(bd, s["team"], s["root_team"], s["root_adv"], s["ply"])

@@ -11,7 +11,7 @@ import oracle_py as O
 import search_lab as SL
 
 pytestmark = pytest.mark.gpu
-CASES = [c for c in SL.load_cases() if c.get("gpu")]
+CASES = [c for c in SL.load_cases() if c.get("gpu") and c["gpu"] != "tree_reuse"]      # tree reuse: its own test below (trees come from searches)
 
 
 class GpuRunner(SL.Runner):
@@ -119,4 +119,55 @@ def test_softmax_robustness_rules_on_gpu(hm):
     p = run([np.nan, 0.0, np.inf, -np.inf] + [0.0] * (n - 4))
     assert p[0] == 0 and p[2] == 0 and p[3] == 0 and abs(float(p.sum(dtype=np.float32)) - 1.0) < 1e-6
     assert np.array_equal(p[[1] + list(range(4, n))], np.full(n - 3, p[1]))
+    eng.close()
+
+
+def _hash_eval_gpu(planes):
+    h = planes.cpu().numpy().view(np.uint16).reshape(-1, 4736)
+    return tuple(torch.from_numpy(x.view(np.float16)).cuda() for x in O.hash_evaluator(h))
+
+
+@pytest.mark.parametrize("pick", ["largest non-principal reply", "smallest reached reply"])
+def test_tree_reuse_adopts_a_non_principal_reply_on_gpu(hm, pick):
+    """EngineTest.TreeReuseRetainsNonPrincipalOpponentReplies (test_move_gen.cc:1332-1391): after a search the selected child AND every
+    reply generated below it stay candidates for the next root; a reply that is NOT the child's principal move is adopted with
+    everything searched beneath it.  The reference builds the tree by hand; the scripted case (search_cases.json) replays that on
+    oracle/search.hpp.  Here the tree comes from a real search: the oracle lists its retained candidates, a non-principal reply is
+    played, and the device (hm_sp_set_tree_reuse + k_begin's find_reusable_root) must adopt that very node — recovered visits equal
+    the candidate's, and the follow-up search equals the oracle's follow-up search from the adopted node, edge for edge."""
+    nodes = 400
+    b = O.Board()
+    s = O.Search(1, 1)
+    s.set_tree_reuse(True)
+    assert s.run(b, 0, False, nodes)
+    first = s.edges()
+    best = s.best_move()
+    ret = s.retained()
+    assert len(ret) >= 3                                                       # the selected child + at least two replies (reference: 3)
+    replies = [r for r in ret[1:] if not r[5] and r[2] >= 1]                   # non-principal, reached (has a position on the device)
+    assert replies, ret
+    rep = max(replies, key=lambda r: r[2]) if pick.startswith("largest") else min(replies, key=lambda r: r[2])
+    eng = hm.SearchEngine(1, 1000)
+    eng.set_games(b.compact(0, False))
+    mode = np.array([1], np.uint8)
+    hm.check(hm.lib.hm_sp_set_tree_reuse(eng.h, mode.ctypes.data, 1))
+    eng.begin_search(nodes)
+    eng.run(_hash_eval_gpu)
+    st = eng.root_stats()
+    n = int(st["counts"][0])
+    assert np.array_equal(st["visits"][0, :n], first["visits"]) and int(st["info"][0, 12]) == best and int(st["info"][0, 16]) == -1
+    own = (int(first["move_a"][best]), int(first["move_b"][best]))
+    eng.apply([own[0]], [own[1]])
+    eng.apply([int(rep[0]) & 0xffffffff], [int(rep[1]) & 0xffffffff])
+    assert b.make_moves(*own) == 0 and b.make_moves(int(rep[0]) & 0xffffffff, int(rep[1]) & 0xffffffff) == 0
+    eng.begin_search(nodes)
+    recovered = int(eng.root_stats()["info"][0, 16])
+    assert recovered == int(rep[2]) >= 1, (recovered, rep)                     # the adopted root IS the retained reply node
+    eng.run(_hash_eval_gpu)
+    assert s.run(b, 0, False, nodes) and s.reused_visits() == recovered
+    st2, e2 = eng.root_stats(), s.edges()
+    n2 = int(st2["counts"][0])
+    assert n2 == len(e2["visits"]) and np.array_equal(st2["visits"][0, :n2], e2["visits"])
+    assert np.array_equal(st2["move_a"][0, :n2], e2["move_a"]) and np.array_equal(st2["q"][0, :n2], e2["q"])
+    assert int(st2["info"][0, 1]) == s.info()["nodes"]
     eng.close()

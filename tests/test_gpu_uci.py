@@ -459,3 +459,34 @@ def test_cli_loop_sees_two_commands_written_at_once():
             p.kill()
     assert best is not None, p.stderr.read().decode()[-2000:]
     assert p.returncode == 0
+
+
+def test_reference_ponder_mode_cases(hm):
+    """PonderModeTest.* of the reference (engine/tests/test_move_gen.cc:1304-1330) on the product's UCI layer:
+    AgentPonderHitTransitions — ponderhit on an engine that is not searching is a safe no-op and leaves it not pondering;
+    SearchOptionsPonderFlags — an ordinary `go` is not a ponder search (it answers by itself), `go ponder` is (silent, running);
+    SearchInfoResetStartTime — the clock of a ponder search restarts at ponderhit: pondering for longer than the move time
+    does not end the search, and after ponderhit it still gets (about) its whole move time."""
+    import time
+    u = hm.Uci(DeviceHashNet(hm), max_nodes=50000)
+    u.command("position startpos moves 1e2e4 2d2d4")
+    assert not u.busy()
+    assert u.command("ponderhit") == ("", False) and not u.busy()          # Agent::ponderhit is safe when not running
+    text, _ = u.command("go nodes 64")                                      # isPonder = false: answers on its own
+    assert text.strip().split("\n")[-1].startswith("bestmove (") and not u.busy()
+    assert u.command("go ponder movetime 250") == ("", False) and u.busy()  # isPonder = true: silent, running
+    time.sleep(0.6)                                                         # more than twice the move time spent pondering
+    assert u.busy() and u.command("")[0] == ""
+    t0 = time.perf_counter()
+    u.command("ponderhit")                                                  # SearchInfo::reset_start_time: the move time starts now
+    text = ""
+    while u.busy() and time.perf_counter() - t0 < 10.0:
+        time.sleep(0.005)
+        text += u.command("")[0]
+    text += u.command("")[0]
+    dt = time.perf_counter() - t0
+    assert text.strip().split("\n")[-1].startswith("bestmove (") and not u.busy(), text
+    infos = [l for l in text.split("\n") if l.startswith("info depth")]
+    t = int(re.search(r" time (\d+) ", infos[-1]).group(1))
+    assert t < 600 and dt < 3.0, (t, dt)                                    # elapsed counts from ponderhit, not from `go`
+    u.close()
