@@ -317,44 +317,82 @@ def main():
         samples = sum_over_ranks(tot["samples"])
         nodes = sum_over_ranks(tot["nodes"])
         it = max(tot["iters"], 1)
-        legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
-                "k_process (expand+backup)": tot["process_ms"] / it}
-        dominant = max(legs, key=legs.get)
-        # the forward evaluates only the rows that hold a leaf (ragged batch, hm_net_forward_groups)
-        rows = tot["eval_rows"] / it
-        net_ms = legs["RISEv3 forward (net)"]
-        ach = rows * flops / (net_ms * 1e-3) / 1e12
-        roof_net = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                    "traffic": None, "kernel": "RISEv3 forward (net)", "kernel_ms": net_ms,
-                    "algorithmic_flops_per_launch": rows * flops, "rows_per_launch": rows}
-        # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node,
-        # plus, per network leaf, the 9472-byte fp16 plane tensor and its legal move lists (4 B per move, counted by the kernel)
-        tree_ms = legs["k_collect (tree traversal)"]
-        by = (tot["nv"] * (64 + 104) + tot["es"] * 40 + tot["lw"] * 4) / it + rows * 9472
-        ach = by / (tree_ms * 1e-3) / 1e9
-        roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_collect (tree traversal)", "kernel_ms": tree_ms, "algorithmic_bytes_per_launch": by,
-                     "note": "latency-bound: one wavefront per game walks its tree with dependent loads; see DESIGN.md"}
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this workload (WRITE_SIZE + 2 x FETCH_SIZE,
-        # separate passes; profiles/r01_selfplay64_pmc_hbm.json) - PMC counters cannot be read from inside the bench
+        persistent = tot["searches"] > 0
         pmc = _pmc_traffic(PMC_SELFPLAY) if (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
-        for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward")):
-            hit = [k for k in pmc if key in k]
-            if hit:
-                r_["traffic"] = sum(pmc[k] for k in hit)
-                r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
-            else:
-                r_["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"
+        if persistent:
+            # Persistent search (hm_sp_search): ONE launch of k_search (a workgroup per game) beside ONE launch of rise_serve (the
+            # evaluator workgroups) per searched ply; both last as long as the ply's slowest game.  `kernel_ms` = average k_search
+            # launch, HIP events on the stream it is launched on (hm_sp_search).  Legs are per game-iteration (device clock).
+            launches = tot["searches"]
+            ks_ms = tot["search_kernel_ms"] / launches
+            legs = {"k_search: collect phase (tree traversal)": tot["collect_ms"] / it, "k_search: wait for the evaluator": tot["wait_ms"] / it,
+                    "k_search: process phase (expand+backup)": tot["process_ms"] / it,
+                    "rise_serve: per position (one workgroup)": tot["eval_ms"] / max(tot["eval_rows"], 1)}
+            dominant = "k_search"
+            # HBM bytes the search needs per launch: the node pool stays in LDS for the whole search (loaded and written back once:
+            # counted with the position records), so per visited path node only its edge record is scanned / updated in HBM (40 B each),
+            # per created node a 232-byte position record is written and read back at the leaf, per network leaf the 9472-byte fp16
+            # plane row and the legal move lists are written (4 B per move) and the evaluator's sorted move / prior arrays read (8 B)
+            by = (tot["es"] * 40 + tot["nv"] * 40 + tot["nodes"] * 2 * 232 + tot["eval_rows"] * 9472 + tot["lw"] * 12) / launches
+            ach = by / (ks_ms * 1e-3) / 1e9
+            roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_search (persistent search: one workgroup per game for a whole search)", "kernel_ms": ks_ms,
+                         "algorithmic_bytes_per_launch": by, "launches": launches,
+                         "note": "latency-bound: a game's descents are a chain of dependent LDS / L2 reads on one wavefront; a launch lasts as long "
+                                 "as its slowest game's search; see DESIGN.md",
+                         "traffic_source": "none: rocprofv3 --pmc runs kernels one at a time, which the two persistent kernels cannot do; the lockstep "
+                                           "kernels' counters (HM_SELFPLAY_LOCKSTEP=1) are kept under profiles/ and in extra.lockstep_pmc_traffic"}
+            fl = tot["eval_rows"] * flops / launches
+            ach = fl / (ks_ms * 1e-3) / 1e12
+            busy_ms = tot["eval_ms"] / max(tot["eval_rows"], 1)
+            roof_net = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "rise_serve (persistent evaluator: one position per workgroup at a time)", "kernel_ms": ks_ms,
+                        "algorithmic_flops_per_launch": fl, "rows_per_launch": tot["eval_rows"] / launches, "busy_ms_per_position": busy_ms,
+                        "TFLOPs_of_one_busy_workgroup": flops / (busy_ms * 1e-3) / 1e12,
+                        "note": "launch duration = the search's; the evaluator idles whenever the games have no batch for it",
+                        "traffic_source": roof_tree["traffic_source"]}
+            if pmc:
+                extra["lockstep_pmc_traffic"] = {"source": PMC_SELFPLAY, "bytes_per_launch": pmc}
+        else:
+            legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
+                    "k_process (expand+backup)": tot["process_ms"] / it}
+            dominant = max(legs, key=legs.get)
+            # the forward evaluates only the rows that hold a leaf (ragged batch, hm_net_forward_groups)
+            rows = tot["eval_rows"] / it
+            net_ms = legs["RISEv3 forward (net)"]
+            ach = rows * flops / (net_ms * 1e-3) / 1e12
+            roof_net = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                        "traffic": None, "kernel": "RISEv3 forward (net)", "kernel_ms": net_ms,
+                        "algorithmic_flops_per_launch": rows * flops, "rows_per_launch": rows}
+            # traversal: 64 B node header + 40 B per scanned edge read per visited node, 64+40 B written back per path node,
+            # plus, per network leaf, the 9472-byte fp16 plane tensor and its legal move lists (4 B per move, counted by the kernel)
+            tree_ms = legs["k_collect (tree traversal)"]
+            by = (tot["nv"] * (64 + 104) + tot["es"] * 40 + tot["lw"] * 4) / it + rows * 9472
+            ach = by / (tree_ms * 1e-3) / 1e9
+            roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_collect (tree traversal)", "kernel_ms": tree_ms, "algorithmic_bytes_per_launch": by,
+                         "note": "latency-bound: one wavefront per game walks its tree with dependent loads; see DESIGN.md"}
+            # HBM traffic per launch from the committed rocprofv3 PMC passes of this workload (WRITE_SIZE + 2 x FETCH_SIZE,
+            # separate passes) - PMC counters cannot be read from inside the bench
+            for r_, key in ((roof_tree, "k_collect"), (roof_net, "rise_forward")):
+                hit = [k for k in pmc if key in k]
+                if hit:
+                    r_["traffic"] = sum(pmc[k] for k in hit)
+                    r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
+                else:
+                    r_["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"
         roof = roof_net if dominant.startswith("RISEv3") else roof_tree
+        extra["search_mode"] = "persistent (k_search + rise_serve, hm_queue.hpp)" if persistent else "lockstep (k_collect || forward -> k_process)"
         extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
-                             "lockstep_iterations": tot["iters"], "leg_ms_per_iteration": legs,
+                             "iterations": tot["iters"], "iteration_unit": "game-iterations (per game: collect -> process)" if persistent else "lockstep iterations (all games)",
+                             "leg_ms_per_iteration": legs,
                              "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9,
                              "persistent_searches": tot["searches"], "search_kernel_ms_total": tot["search_kernel_ms"], "wait_ms_total": tot["wait_ms"],
                              "wall_split_s": {"run": tot["seconds"], "search": tot["search_s"], "prologue": tot["prologue_s"], "raw_policy": tot["raw_s"]}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_selfplay_baseline(model, args.nodes)
-        line = dict(metric="self-play positions/sec @ nodes=400", value=samples / dt, unit="positions/s", steps=args.steps,
+        line = dict(metric=f"self-play positions/sec @ nodes={args.nodes}", value=samples / dt, unit="positions/s", steps=args.steps,
                     warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, dtype="fp16 net / u64 board / f32 tree",
                     config={"workload": f"selfplay --games {args.games} --nodes {args.nodes} per GPU, random-init RISEv3-{args.model} "
                                         f"(torch.manual_seed(0)), B=8 single-thread reference schedule per game",
