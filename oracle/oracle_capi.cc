@@ -275,6 +275,13 @@ int ora_pw_allowed_children(int visits, int isRoot) { return get_allowed_childre
 float ora_get_cpuct(float v) { return get_cpuct(v, 2.5f, 19652.0f); }
 float ora_portable_expf(float x) { return portable_expf(x); }
 
+// timing helper of tools/cpu_baseline.py: `reps` calls of Board::legal_moves(b) on this position; returns the moves counted
+long long ora_time_legal_moves(void* h, int b, int reps) {
+    Board& board = *static_cast<Board*>(h);
+    long long n = 0;
+    for (int r = 0; r < reps; ++r) n += (long long)board.legal_moves(b).size();
+    return n;
+}
 // timing helpers for bench.py's cpu_baseline leg
 double ora_time_planes(const hm_board* boards, size_t n, int dtype, void* out, int reps) {
     auto t0 = std::chrono::steady_clock::now();

@@ -140,6 +140,13 @@ static long long perft1_rec(Board& board, int b, int depth) {
     return n;
 }
 long long ref_perft_single(void* h, int b, int depth) { return perft1_rec(*static_cast<Board*>(h), b, depth); }
+// timing helper of tools/cpu_baseline.py: `reps` calls of Board::legal_moves(b) on this position; returns the moves counted
+long long ref_time_legal_moves(void* h, int b, int reps) {
+    Board& board = *static_cast<Board*>(h);
+    long long n = 0;
+    for (int r = 0; r < reps; ++r) n += (long long)board.legal_moves(b).size();
+    return n;
+}
 
 void ref_policy_tables(int* normal /*2*64*64*2*/, int* drop /*2*64*8*/) {
     ref_init();

@@ -43,6 +43,7 @@ print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searche
                       eval_rows=res.eval_rows, eval_batches=res.eval_batches, iters=res.search_iterations, raw=res.raw_plies,
                       seconds=res.seconds, wall=dt, positions_per_s=res.samples / res.seconds, nodes_per_s=res.total_nodes / res.seconds,
                       term=list(res.terminations), bytes=res.record_bytes, chunk_samples=len(samples),
+                      persistent_searches=res.persistent_searches, search_kernel_ms=res.search_kernel_ms, wait_ms=res.wait_ms,
                       leg_ms=dict(collect=res.collect_ms / max(res.search_iterations, 1), net=res.eval_ms / max(res.search_iterations, 1),
                                   process=res.process_ms / max(res.search_iterations, 1)),
                       iter_ms=res.seconds * 1e3 / max(res.eval_batches, 1), search_iter_ms=res.search_seconds * 1e3 / max(res.search_iterations, 1),
