@@ -19,6 +19,10 @@ unset HM_SELFPLAY_LOCKSTEP
 PL="python3 $ROOT/bench.py --workload planes --steps 3 --warmup 1 --no-cpu-baseline"
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $ROOT/gpurun_out/pmc_pw -o w -- $PL > $ROOT/gpurun_out/pmc_pw.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $ROOT/gpurun_out/pmc_pf -o f -- $PL > $ROOT/gpurun_out/pmc_pf.log 2>&1
+PF="python3 $ROOT/tools/run_perft.py 5"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/perft_ks -o ks -- $PF > $ROOT/gpurun_out/perft_ks.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES --output-format csv -d $ROOT/gpurun_out/perft_sq -o sq -- $PF > $ROOT/gpurun_out/perft_sq.log 2>&1
 cd $ROOT
-find gpurun_out/ks -name '*kernel_trace.csv' -size +40M -delete
+timeout -k 10 300 python3 tools/cpu_baseline.py --json gpurun_out/cpu_baseline_gpuhost.json > gpurun_out/cpu_baseline_gpuhost.log 2>&1
+find gpurun_out/ks gpurun_out/perft_ks -name '*kernel_trace.csv' -size +40M -delete
 cat gpurun_out/bench_line.json
