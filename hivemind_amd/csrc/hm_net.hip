@@ -999,7 +999,7 @@ __global__ __launch_bounds__(512, 1) void rise_serve(const NetDesc* __restrict__
     const NetDesc& nd = *ndp;
     int dbgN = 0;
     unsigned long long ticks = 0, count = 0;
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.q->consIn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(hmq::G32(&a.q->consIn), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         if (threadIdx.x == 0) {
             const unsigned it = hmq::pop_item(a.q);
@@ -1019,14 +1019,14 @@ __global__ __launch_bounds__(512, 1) void rise_serve(const NetDesc* __restrict__
         hmq::drain_stores();                                        // every wave's write-through stores of the heads have left
         __syncthreads();                                            // (also: every thread has read s_item)
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(&a.done[g * 2 + buf], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(hmq::G32(&a.done[g * 2 + buf]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ticks += __builtin_amdgcn_s_memrealtime() - t0; ++count;
         }
     }
     if (threadIdx.x == 0) {
         if (a.clkSum && count) { atomicAdd(a.clkSum, ticks); atomicAdd(a.clkCnt, count); }
-        __hip_atomic_fetch_add(&a.q->served, (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&a.q->consOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(hmq::G32(&a.q->served), (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(hmq::G32(&a.q->consOut), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 #undef HM_STAMP

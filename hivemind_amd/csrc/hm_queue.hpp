@@ -25,6 +25,13 @@ typedef unsigned long long u64q;
 constexpr int QCAP = 8192;                   // ring slots (power of two) >> rows in flight (16 per game) + idle consumers
 constexpr u64q SPIN_LIMIT_TICKS = 2000000000ULL;   // 20 s of the 100 MHz s_memrealtime counter: a hang guard, not a schedule
 constexpr u64q MEET_LIMIT_TICKS = 300000000ULL;    // 3 s: by then the other kernel of the pair must have started (error 4: not concurrent)
+// When NO row has been published for this long (the tail has not moved) while search workgroups are still running, a waiting
+// evaluator workgroup declares the search stalled (error 5): a game's collect phase lasts ~0.1 ms, so even one live game moves
+// the tail several times per millisecond (a workgroup far back in the line may itself wait much longer for its turn).  Observed on
+// MI355X with the deployed network about once in 800 searches: the search workgroups stop making progress (in whatever phase they
+// are in, all published rows evaluated, every counter consistent) until the evaluator kernel has left the device; the caller then
+// repeats that search (hm_sp_search_stalled / hm_sp_begin_again), which costs one search and changes no result.
+constexpr u64q IDLE_LIMIT_TICKS = 3000000ULL;      // 30 ms
 
 // item payload (low 32 bits of a slot): game slot, plane buffer, row, evaluator-specific flags
 constexpr unsigned IT_POISON = 0x80000000u;  // no more work: the consumer leaves
@@ -41,14 +48,23 @@ struct SrvQueue {                            // one per search engine; zeroed (w
     unsigned producers;                      // search workgroups still running (set by the host after the memset)
     unsigned error;                          // != 0: some spin gave up (code of the first), everybody leaves
     unsigned consumers;                      // evaluator workgroups of this launch (poison count)
+    unsigned games;                          // game slots: behind the slots lie done[2G], progress[3G], heartbeats[4G] and a snapshot[7G] of the last two
     unsigned served;                         // items evaluated (statistics)
     unsigned treesIn, treesOut, consIn, consOut;   // census of both kernels (diagnostics of a give-up)
     unsigned dbg[6];                         // first failed wait of a search workgroup: game, buffer, rows expected, rows done, iteration, ms since the kernel's first workgroup started
+    unsigned dupTickets;                     // pushes that found their slot already carrying their own ticket's tag (diagnostics: two producers drew one ticket)
+    unsigned dbgPop[2];                      // the evaluator workgroup that gave up (error 2): its ticket, the tail and head it saw then, ms waited
     u64q slots[QCAP];                        // {ticket + 1, payload}
 };
 static_assert(sizeof(SrvQueue) % 16 == 0, "zeroed as one block of 16-byte multiples");
 
 #define HMQ_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// Every word two workgroups share is accessed as GLOBAL memory (address space 1: global_* instructions), never through a generic
+// pointer (flat_*: the queue pointer often comes out of LDS or a by-value struct, where the compiler cannot infer the address space).
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) u64q gu64;
+__device__ __forceinline__ gu32* G32(const unsigned* p) { return (gu32*)(p); }
+__device__ __forceinline__ gu64* G64(const u64q* p) { return (gu64*)(p); }
 
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ONE lane, after every storing wave has drained and the workgroup has met at a barrier
@@ -69,38 +85,57 @@ typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_wt(void* p, u32x4q v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void store2_wt(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, HMQ_RLX); }
+__device__ __forceinline__ void store2_wt(uint16_t* p, uint16_t v) { __hip_atomic_store((__attribute__((address_space(1))) uint16_t*)(p), v, HMQ_RLX); }
 __device__ __forceinline__ bool spin_expired(u64q t0) { return (u64q)__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS; }
 
 // producer, ONE lane (release done): n items with consecutive tickets
 __device__ __forceinline__ void push_items(SrvQueue* q, const unsigned* items, int n) {
-    const unsigned t = __hip_atomic_fetch_add(&q->tail, (unsigned)n, HMQ_RLX);
-    for (int i = 0; i < n; ++i)
-        __hip_atomic_store(&q->slots[(t + i) & (QCAP - 1)], ((u64q)(t + i + 1) << 32) | items[i], HMQ_RLX);
+    const unsigned t = __hip_atomic_fetch_add(G32(&q->tail), (unsigned)n, HMQ_RLX);
+    for (int i = 0; i < n; ++i) {
+        const u64q old = __hip_atomic_exchange(G64(&q->slots[(t + i) & (QCAP - 1)]), ((u64q)(t + i + 1) << 32) | items[i], HMQ_RLX);
+        if ((unsigned)(old >> 32) == t + i + 1) __hip_atomic_fetch_add(G32(&q->dupTickets), 1u, HMQ_RLX);
+    }
 }
 // the last producer to leave releases every consumer (ONE lane)
 __device__ __forceinline__ void producer_exit(SrvQueue* q) {
-    if (__hip_atomic_fetch_sub(&q->producers, 1u, HMQ_RLX) != 1u) return;
-    const unsigned n = __hip_atomic_load(&q->consumers, HMQ_RLX);
-    const unsigned t = __hip_atomic_fetch_add(&q->tail, n, HMQ_RLX);
+    if (__hip_atomic_fetch_sub(G32(&q->producers), 1u, HMQ_RLX) != 1u) return;
+    const unsigned n = __hip_atomic_load(G32(&q->consumers), HMQ_RLX);
+    const unsigned t = __hip_atomic_fetch_add(G32(&q->tail), n, HMQ_RLX);
     for (unsigned i = 0; i < n; ++i)
-        __hip_atomic_store(&q->slots[(t + i) & (QCAP - 1)], ((u64q)(t + i + 1) << 32) | IT_POISON, HMQ_RLX);
+        (void)__hip_atomic_exchange(G64(&q->slots[(t + i) & (QCAP - 1)]), ((u64q)(t + i + 1) << 32) | IT_POISON, HMQ_RLX);
 }
 // consumer, ONE lane: next item (blocks; IT_POISON on shutdown, error or give-up).  No acquire yet.
 __device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
-    const unsigned t = __hip_atomic_fetch_add(&q->head, 1u, HMQ_RLX);
+    const unsigned t = __hip_atomic_fetch_add(G32(&q->head), 1u, HMQ_RLX);
     u64q* slot = &q->slots[t & (QCAP - 1)];
     const u64q t0 = __builtin_amdgcn_s_memrealtime();
+    u64q tMoved = t0;                        // when the tail was last seen to move
+    unsigned tailSeen = ~0u;
     for (unsigned spins = 0;; ++spins) {
-        const u64q v = __hip_atomic_load(slot, HMQ_RLX);
+        const u64q v = __hip_atomic_load(G64(slot), HMQ_RLX);
         if ((unsigned)(v >> 32) == t + 1) return (unsigned)v;
         __builtin_amdgcn_s_sleep(8);
         if ((spins & 255u) == 255u) {
-            if (__hip_atomic_load(&q->error, HMQ_RLX)) return IT_POISON;
+            if (__hip_atomic_load(G32(&q->error), HMQ_RLX)) return IT_POISON;
             const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
             // no search workgroup has started while this one has been waiting: the two kernels are being run one after the other
-            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(&q->treesIn, HMQ_RLX) == 0u) { __hip_atomic_store(&q->error, 4u, HMQ_RLX); return IT_POISON; }
-            if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(&q->error, 2u, HMQ_RLX); return IT_POISON; }
+            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(G32(&q->treesIn), HMQ_RLX) == 0u) { __hip_atomic_store(G32(&q->error), 4u, HMQ_RLX); return IT_POISON; }
+            const unsigned tailNow = __hip_atomic_load(G32(&q->tail), HMQ_RLX);
+            if (tailNow != tailSeen) { tailSeen = tailNow; tMoved = t0 + waited; }
+            const bool stalled = t0 + waited - tMoved > IDLE_LIMIT_TICKS && __hip_atomic_load(G32(&q->producers), HMQ_RLX) != 0u;
+            if (stalled || waited > SPIN_LIMIT_TICKS) {
+                if (atomicCAS(&q->dbgPop[0], 0u, t + 1u) == 0u) {
+                    q->dbgPop[1] = __hip_atomic_load(G32(&q->tail), HMQ_RLX);
+                    // where every game stands NOW, before the error word lets anybody go
+                    const unsigned G = __hip_atomic_load(G32(&q->games), HMQ_RLX);
+                    unsigned* live = reinterpret_cast<unsigned*>(q + 1) + 2 * G;
+                    unsigned* snap = live + 7 * G;
+                    for (unsigned i = 0; i < 7 * G; ++i) snap[i] = __hip_atomic_fetch_add(G32(&live[i]), 0u, HMQ_RLX);
+                    snap[2 * G] = (unsigned)((u64q)__builtin_amdgcn_s_memrealtime() / 1000ULL);   // (slot 0's exit stamp is not needed: the time of the snapshot)
+                }
+                __hip_atomic_store(G32(&q->error), stalled ? 5u : 2u, HMQ_RLX);
+                return IT_POISON;
+            }
         }
     }
 }
@@ -108,14 +143,14 @@ __device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
 __device__ __forceinline__ bool wait_count(SrvQueue* q, unsigned* counter, unsigned want) {
     const u64q t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(counter, HMQ_RLX) >= want) return true;
+        if (__hip_atomic_load(G32(counter), HMQ_RLX) >= want) return true;
         __builtin_amdgcn_s_sleep(4);
         if ((spins & 255u) == 255u) {
-            if (__hip_atomic_load(&q->error, HMQ_RLX)) return false;
+            if (__hip_atomic_load(G32(&q->error), HMQ_RLX)) return false;
             const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
             // no evaluator workgroup has started in all that time: the two kernels are being run one after the other
-            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(&q->consIn, HMQ_RLX) == 0u) { __hip_atomic_store(&q->error, 4u, HMQ_RLX); return false; }
-            if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(&q->error, 3u, HMQ_RLX); return false; }
+            if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(G32(&q->consIn), HMQ_RLX) == 0u) { __hip_atomic_store(G32(&q->error), 4u, HMQ_RLX); return false; }
+            if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(G32(&q->error), 3u, HMQ_RLX); return false; }
         }
     }
 }

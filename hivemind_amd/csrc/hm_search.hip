@@ -185,6 +185,12 @@ struct Pools {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
+__device__ unsigned int* g_hb;                    // diagnostics of a persistent-search give-up: last heartbeat code per (game slot, wave); nullptr outside k_search
+#ifdef HM_SEARCH_HB
+#define HB(c) do { unsigned int* hb_ = g_hb; if ((threadIdx.x & 63) == 0 && hb_) __hip_atomic_store(hmq::G32(&hb_[blockIdx.x * 4 + (threadIdx.x >> 6)]), (unsigned)(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define HB(c) do { } while (0)
+#endif
 __device__ unsigned long long g_prof[128];     // hm_prof.hpp probes: 64 sums + 64 call counts (all zero in the product build)
 #ifdef HM_SEARCH_PROF
 constexpr int PROF_LAUNCHES = 8192;
@@ -244,8 +250,10 @@ __device__ __forceinline__ void mark_dirty(const G& s, int id) { if (s.dirty) s.
 __device__ __forceinline__ void svc_wait(G& s) {
     if (s.inflight < 0) return;
     PROF_T(tsw);
+    HB(11);
     while (__hip_atomic_load(s.typeSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.reqSeq) __builtin_amdgcn_s_sleep(1);
     s.inflight = -1;
+    HB(16);
     PROF_ADD(19, tsw);
 }
 // blocks until the classifier wave has finished the outstanding request entirely (context record, board image, counters)
@@ -253,15 +261,19 @@ __device__ __forceinline__ void svc_wait(G& s) {
 __device__ __forceinline__ void svc_join(G& s, int behind = 0) {
     if (!s.svcBusy) return;
     PROF_T(tsw);
+    HB(12);
     while (__hip_atomic_load(s.ackSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < s.reqSeq - behind) __builtin_amdgcn_s_sleep(1);
     if (behind == 0) { s.inflight = -1; s.svcBusy = false; }
+    HB(17);
     PROF_ADD(22, tsw);
 }
 __device__ __forceinline__ void gen_wait(G& s) {
     if (s.genInflight < 0) return;
     PROF_T(tgw);
+    HB(13);
     while (__hip_atomic_load(s.genAckSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.genReqSeq) __builtin_amdgcn_s_sleep(1);
     s.genInflight = -1;
+    HB(18);
     PROF_ADD(21, tgw);
 }
 __device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
@@ -1200,7 +1212,7 @@ __device__ __forceinline__ void post_arrive(WaveLds& L, const PubCtx* pc, int po
     __hip_atomic_store(&L.postReady[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (now & 4) {
         const unsigned item = pc->itemBase | ((unsigned)L.postRow[slot] << 21);
-        atomicAdd(pc->expect, 1u);
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned*)(pc->expect), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // LDS (k_search's s_expect)
         hmq::push_items(pc->q, &item, 1);
     }
 }
@@ -1232,6 +1244,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     if (reserved) {
         const int np_ = L.postCount;
         myPost = np_;
+        HB(22);
         while (np_ - min(__hip_atomic_load(&L.servedCnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP),
                          __hip_atomic_load(&L.servedCntB, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= BATCH) __builtin_amdgcn_s_sleep(1);   // ring slot free
         hm_board* hb = reinterpret_cast<hm_board*>(L.board[np_ & (BATCH - 1)]);
@@ -1253,6 +1266,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
         if (lane == 0) __hip_atomic_store(&L.posted, np_ + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     int endInPly = 0, result = 0, newValid = valid;
+    HB(23);
     const int to = classify_terminal_position(rt, p.jb, ctx.team, rootTeam, rootAdv, searchPly, &endInPly, &L.lists[0][0]);
     if (to != 0) {
         ctx.terminal = 1;
@@ -1268,7 +1282,9 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     if (lane == 0) L.reqResult = result;
     wave_fence();
     if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    HB(24);
     if constexpr (WT) { if (myPost >= 0) post_arrive(L, pc, myPost, result == 0 ? 4 : 8); }
+    HB(25);
     PROF_ADD_T(24, tsv, 64);
     if (result == 0) {
         const bool leafAdv = ctx.team == rootTeam ? rootAdv : !rootAdv;
@@ -1293,6 +1309,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
     TRACE_SEQ();
     while (nctx < BATCH && attempts < BATCH * 2) {
         attempts++;
+        HB(100 + attempts);
         PROF_T(t0);
         bool reserved = false;
         const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
@@ -1481,7 +1498,7 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
                 // the position is at hand, so that whoever sorts the priors needs only the list
                 const u32 v = m | (is_capture(p, m) ? hmp::CAPTURE_BIT : 0u);
                 u32* q = dst + kept + __popcll(km & ((1ULL << lane) - 1ULL));
-                if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the evaluator's workgroup
+                if constexpr (WT) __hip_atomic_store(hmq::G32(q), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by the evaluator's workgroup
                 else *q = v;
             }
             kept += __popcll(km);
@@ -1490,7 +1507,7 @@ __device__ inline void leaf_move_list(const Pools& pl, const RulesTab& rt, WaveL
     }
     if (lane == 0) {
         const int v = kept | ((int)p.stm << 16);
-        if constexpr (WT) __hip_atomic_store(&pl.leafCounts[base + b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (WT) __hip_atomic_store(hmq::G32(reinterpret_cast<const unsigned*>(&pl.leafCounts[base + b])), (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else pl.leafCounts[base + b] = v;
         atomicAdd(&L.listWords, kept);
     }
@@ -1513,10 +1530,13 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 if (rs == seen) break;
             }
             seen++;                                                // requests are served one by one, in order
+            HB(21);
             serve_leaf<WT>(s, s_rt, L, rootTeam, rootAdv, seen, pc);
+            HB(26);
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        HB(29);
     } else if (wave == 3) {
         // generator wave: the two successor pushes of every pair the traversal pops (joint_action.h:312-328) and, between
         // them, the board-B legal move list of every posted leaf image (the plane-writer wave does the planes and board A)
@@ -1527,6 +1547,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 const int node = L.gq.node, iA = L.gq.iA, iB = L.gq.iB;
                 GenHdr* gh = reinterpret_cast<GenHdr*>(s.arena + L.gq.genOff);
                 GenHdr h = *gh;
+                HB(41);
                 gen_push(s, h, iA + 1, iB);
                 gen_push(s, h, iA, iB + 1);
                 *gh = h;
@@ -1534,13 +1555,17 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 wave_fence();
                 seen = rs;
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.gq.ackSeq, rs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                HB(40);
                 continue;
             }
             const int posted = __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (servedB < posted) {
                 const int img = servedB & (BATCH - 1);
+                HB(42);
                 leaf_move_list<WT>(pl, s_rt, L, g, img, L.postRow[img], 1);
-                if constexpr (WT) { hmq::drain_stores(); post_arrive(L, pc, servedB, 1); }
+                HB(43);
+                if constexpr (WT) { hmq::drain_stores(); HB(44); post_arrive(L, pc, servedB, 1); }
+                HB(45);
                 servedB++;
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCntB, servedB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
@@ -1551,6 +1576,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 && __hip_atomic_load(&L.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == servedB) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        HB(49);
     } else {
         uint16_t* dst = planesNext + (size_t)g * BATCH * HM_PLANE_VALUES;
         int served = 0;
@@ -1562,12 +1588,17 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
                 if (served >= posted) break;
             }
             const int img = served & (BATCH - 1), row = L.postRow[img];
+            HB(31);
             write_planes_f16<WT>(s_rt, L.board[img], reinterpret_cast<uint4*>(dst + (size_t)row * HM_PLANE_VALUES), L.pmask, L.pval);
+            HB(32);
             leaf_move_list<WT>(pl, s_rt, L, g, img, row, 0);
-            if constexpr (WT) { hmq::drain_stores(); post_arrive(L, pc, served, 1); }
+            HB(33);
+            if constexpr (WT) { hmq::drain_stores(); HB(34); post_arrive(L, pc, served, 1); }
+            HB(35);
             served++;
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.servedCnt, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        HB(39);
     }
 }
 
@@ -1714,6 +1745,7 @@ struct SearchIo {
     NetOut out[2];                           // heads of buffer 0 / 1 (rows g * BATCH + slot)
     hmq::SrvQueue* q;
     unsigned* done;                          // [nGames][2] rows evaluated per (game, buffer), cumulative over the search
+    unsigned* progress;                      // [2][nGames] diagnostics of a give-up: phase | iteration << 8, and its time stamp (10 us units)
     const uint8_t* netSel;                   // per game: evaluator index of its items (nullptr: 0)
     int ldsNodes;                            // the node pool fits in LDS beside k_search's static LDS
 };
@@ -1752,9 +1784,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     if (threadIdx.x == 0) { s_expect[0] = s_expect[1] = 0; s_ctl.action = ACT_COLLECT; s_ctl.buf = 0; s_ctl.first = 1; s_ctl.ok = 1; L.listWords = 0; }
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&io.q->treesIn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(hmq::G32(&io.q->treesIn), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!searching) {                                               // idle slot, or a search k_begin already settled
-        if (threadIdx.x == 0) { __hip_atomic_fetch_add(&io.q->treesOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hmq::producer_exit(io.q); }
+        if (threadIdx.x == 0) { __hip_atomic_fetch_add(hmq::G32(&io.q->treesOut), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hmq::producer_exit(io.q); }
         return;
     }
     const bool mirror = io.ldsNodes != 0;
@@ -1775,6 +1807,13 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     ExpLds& myExp = wave <= 1 ? L.exp : s_exp2[wave - 2];
     const PreSorted pre{pl.sortedMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES, pl.sortedPriors + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES};
     u64 tC = 0, tW = 0, tP = 0, nIt = 0;                            // thread 0: ticks spent collecting / waiting for the evaluator / processing
+    unsigned xcc;                                                   // which XCD this workgroup runs on (diagnostics of a give-up)
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    auto mark = [&](unsigned phase) {                               // thread 0 only
+        __hip_atomic_store(hmq::G32(&io.progress[g]), phase | (xcc << 4) | ((unsigned)nIt << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hmq::G32(&io.progress[gridDim.x + g]), (unsigned)((u64)__builtin_amdgcn_s_memrealtime() / 1000ULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // process of the pending batch: wait for its evaluation (unless `abortIt`), backups on wave 0 beside the expansions on waves 1..3
     auto process_pending = [&](bool abortIt) -> bool {
         const int pending = s_game.pending;
@@ -1782,16 +1821,18 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         if (threadIdx.x == 0) {
             t0 = __builtin_amdgcn_s_memrealtime();
             bool ok = true;
+            mark(3u);
             if (!abortIt && s_game.validCount[pending] > 0) {
                 ok = hmq::wait_count(io.q, &io.done[g * 2 + pending], s_expect[pending]);
                 if (ok) hmq::acquire_agent();
                 else if (atomicCAS(&io.q->dbg[0], 0u, (unsigned)g + 1u) == 0u) {
                     io.q->dbg[1] = (unsigned)pending; io.q->dbg[2] = s_expect[pending];
-                    io.q->dbg[3] = __hip_atomic_load(&io.done[g * 2 + pending], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    io.q->dbg[3] = __hip_atomic_load(hmq::G32(&io.done[g * 2 + pending]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     io.q->dbg[4] = (unsigned)nIt; io.q->dbg[5] = (unsigned)(((u64)__builtin_amdgcn_s_memrealtime() - t0) / 100000ULL);
                 }
             }
             s_ctl.ok = ok ? 1 : 0;
+            if (ok) mark(4u); else io.progress[g] = 5u | (xcc << 4) | ((unsigned)nIt << 8);     // 5: the wait failed (the stamp stays at its start)
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
             tW += t1 - t0; t0 = t1;
         }
@@ -1856,24 +1897,28 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         const int buf = s_ctl.buf;
         const bool first = s_ctl.first != 0;
         u64 t0 = 0;
-        if (threadIdx.x == 0) t0 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); mark(1u); }
         // ---- collect phase (collect_batch, searchthread.cc:255-442) into plane buffer `buf`
         PROF_T(tcp);
         if (wave == 0) {
             s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0;
             collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
             if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            HB(19);
         } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave, &s_pub);
         PROF_ADD(33, tcp);
         PROF_T(tcd);
         hmq::drain_stores();                                        // the write-through stores of this batch's plane rows have left every wave
+        HB(50 + (threadIdx.x >> 6));
         __syncthreads();
+        HB(60);
         PROF_ADD(39, tcd);
         PROF_ADD(32, tcp);
         PROF_T(tpu);
         if (threadIdx.x == 0) {                                     // (the batch's rows went to the evaluator one by one: post_arrive)
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
             tC += t1 - t0; nIt++;
+            mark(2u);
         }
         PROF_ADD(34, tpu);
         if (first) {
@@ -1918,7 +1963,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         LegClock* ck = pl.clk;                                      // per game-iteration sums (100 MHz ticks)
         atomicAdd(&ck->sumC, tC); atomicAdd(&ck->sumW, tW); atomicAdd(&ck->sumP, tP);
         atomicAdd(&ck->cntC, nIt); atomicAdd(&ck->cntP, nIt);
-        __hip_atomic_fetch_add(&io.q->treesOut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        io.progress[2 * gridDim.x + g] = (unsigned)((u64)__builtin_amdgcn_s_memrealtime() / 1000ULL);   // when it left
+        io.progress[3 * gridDim.x + g] = s_expect[0] + s_expect[1] + 1u;                              // rows it published (+ 1), over the heartbeat words of wave 0..3 of slot g / 4: diagnostics only
+        __hip_atomic_fetch_add(hmq::G32(&io.q->treesOut), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         hmq::producer_exit(io.q);
     }
     PROF_FLUSH();
@@ -1932,11 +1979,11 @@ __global__ void k_wait_trees(hmq::SrvQueue* q, unsigned trees) {
     if (threadIdx.x != 0) return;
     const hmq::u64q t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(&q->treesIn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= trees) return;
+        if (__hip_atomic_load(hmq::G32(&q->treesIn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= trees) return;
         __builtin_amdgcn_s_sleep(2);
         if ((spins & 255u) == 255u) {
-            if (__hip_atomic_load(&q->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-            if ((hmq::u64q)__builtin_amdgcn_s_memrealtime() - t0 > hmq::MEET_LIMIT_TICKS) { __hip_atomic_store(&q->error, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+            if (__hip_atomic_load(hmq::G32(&q->error), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            if ((hmq::u64q)__builtin_amdgcn_s_memrealtime() - t0 > hmq::MEET_LIMIT_TICKS) { __hip_atomic_store(hmq::G32(&q->error), 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         }
     }
 }
@@ -2765,7 +2812,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     }
     rc |= dalloc(sp, &sp->d_rootHash, 2 * G_); rc |= dalloc(sp, &sp->d_active, 2) /* [0] active games */;
     {
-        sp->queueBytes = sizeof(hmq::SrvQueue) + ((G_ * 2 * sizeof(unsigned) + 15) & ~(size_t)15);
+        sp->queueBytes = sizeof(hmq::SrvQueue) + ((G_ * 16 * sizeof(unsigned) + 15) & ~(size_t)15);   // + done[G][2], progress[G], stamp[G]
         rc |= dalloc(sp, &sp->d_queue, sp->queueBytes);
         hipFuncAttributes fa;
         size_t staticLds = 64 * 1024;
@@ -2931,6 +2978,9 @@ int hm_sp_begin_again(hm_sp* sp) {
 // 1 when the last hm_sp_search failed because its two kernels were run one after the other (a serialising profiler, or a
 // runtime that put both streams on one hardware queue): the lockstep calls still work.
 int hm_sp_search_not_concurrent(const hm_sp* sp) { return sp && sp->lastQueueError == 4u ? 1 : 0; }
+// 1 when the last hm_sp_search was given up because the evaluator had nothing to do for 30 ms while games were still searching
+// (hm_queue.hpp: IDLE_LIMIT_TICKS): hm_sp_begin_again + another search (persistent or lockstep) repeats it with the same result.
+int hm_sp_search_stalled(const hm_sp* sp) { return sp && sp->lastQueueError == 5u ? 1 : 0; }
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
@@ -2963,7 +3013,9 @@ int hm_sp_search_consumers(const hm_sp* sp) {
     // every CU the game workgroups leave: a workgroup of either kernel takes a whole CU (the search kernel the full register file,
     // the evaluator most of it), the games are placed first (k_wait_trees), and an evaluator workgroup that finds no CU only waits
     const int slots = sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames;
-    const int n = sp->numCUs - std::min(slots, sp->nGames);
+    const int act = std::min(slots, sp->nGames);
+    // no more of them than rows can be in flight (two batches of BATCH rows per searching game, and a few to spare)
+    const int n = std::min(sp->numCUs - act, 2 * BATCH * act + 8);
     return (sp->numCUs - sp->nGames) >= 8 && n >= 8 ? n : 0;
 }
 
@@ -3003,9 +3055,15 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     unsigned* done = reinterpret_cast<unsigned*>(sp->d_queue + sizeof(hmq::SrvQueue));
     // every polled word starts from zero; then the two head counts (producers .. consumers are adjacent words)
     HIPCHK(hipMemsetAsync(sp->d_queue, 0, sp->queueBytes, sT));
-    sp->h_qinit[0] = (unsigned)sp->nGames; sp->h_qinit[1] = 0u; sp->h_qinit[2] = (unsigned)consumers;
-    static_assert(offsetof(hmq::SrvQueue, error) == offsetof(hmq::SrvQueue, producers) + 4 && offsetof(hmq::SrvQueue, consumers) == offsetof(hmq::SrvQueue, producers) + 8, "queue header layout");
-    HIPCHK(hipMemcpyAsync(&q->producers, sp->h_qinit, 12, hipMemcpyHostToDevice, sT));
+    sp->h_qinit[0] = (unsigned)sp->nGames; sp->h_qinit[1] = 0u; sp->h_qinit[2] = (unsigned)consumers; sp->h_qinit[3] = (unsigned)sp->nGames;
+#ifdef HM_SEARCH_HB
+    {
+        unsigned* hbp = done + (size_t)sp->nGames * 5;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_hb), &hbp, sizeof(hbp)));
+    }
+#endif
+    static_assert(offsetof(hmq::SrvQueue, error) == offsetof(hmq::SrvQueue, producers) + 4 && offsetof(hmq::SrvQueue, consumers) == offsetof(hmq::SrvQueue, producers) + 8 && offsetof(hmq::SrvQueue, games) == offsetof(hmq::SrvQueue, producers) + 12, "queue header layout");
+    HIPCHK(hipMemcpyAsync(&q->producers, sp->h_qinit, 16, hipMemcpyHostToDevice, sT));
     HIPCHK(hipEventRecord(sp->evFork, sT));
     HIPCHK(hipStreamWaitEvent(sN, sp->evFork, 0));
     hmq::ServeArgs a;
@@ -3023,7 +3081,7 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     SearchIo sio;
     sio.planes[0] = static_cast<uint16_t*>(io->planes[0]); sio.planes[1] = static_cast<uint16_t*>(io->planes[1]);
     for (int b = 0; b < 2; ++b) sio.out[b] = NetOut{a.value[b], a.piA[b], a.piB[b], a.wdl[b], a.ml[b]};
-    sio.q = q; sio.done = done; sio.netSel = nullptr; sio.ldsNodes = sp->searchLdsNodes;
+    sio.q = q; sio.done = done; sio.progress = done + (size_t)sp->nGames * 2; sio.netSel = nullptr; sio.ldsNodes = sp->searchLdsNodes;
     (void)hipEventRecord(sp->evT0, sT);            // HIP events on the stream the kernel is launched on: its launch duration
     hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
     const hipError_t le = hipGetLastError();
@@ -3041,6 +3099,12 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     }
     HIPCHK(hipStreamSynchronize(sT));
     HIPCHK(hipStreamSynchronize(sN));
+#ifdef HM_SEARCH_HB
+    {
+        unsigned* hbp = nullptr;                                       // the lockstep kernels share the device functions
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_hb), &hbp, sizeof(hbp)));
+    }
+#endif
     if (search_kernel_ms) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, sp->evT0, sp->evT1) == hipSuccess) *search_kernel_ms = ms; else { *search_kernel_ms = 0.0; (void)hipGetLastError(); }
@@ -3048,13 +3112,53 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     hmq::SrvQueue hq;                                              // header only (the slots follow it)
     HIPCHK(hipMemcpy(&hq, q, offsetof(hmq::SrvQueue, slots), hipMemcpyDeviceToHost));
     sp->lastQueueError = hq.error;
-    if (hq.error)
+    if (!hq.error) {
+        // test hook: HM_SEARCH_FAKE_STALL_EVERY=k reports every k-th completed persistent search as stalled, so that the caller's
+        // recovery path (hm_sp_search_stalled -> hm_sp_begin_again -> the search once more) runs on demand
+        const char* fe = std::getenv("HM_SEARCH_FAKE_STALL_EVERY");
+        const int fakeEvery = fe ? std::atoi(fe) : 0;
+        static int fakeCount = 0;
+        if (fakeEvery > 0 && ++fakeCount % fakeEvery == 0) {
+            sp->lastQueueError = 5u;
+            return hm_fail(HM_ERR_STATE, "persistent search reported as stalled (HM_SEARCH_FAKE_STALL_EVERY)");
+        }
+    }
+    if (hq.error) {
+        // where every game that had work stood when the search was given up (phase: 1 collecting, 2 collected, 3 waiting for the evaluator, 4 processing, 5 the wait failed; since when; when it left)
+        const size_t G_ = (size_t)sp->nGames;
+        std::string census;
+        {   // rows the games published (their own count) against the tickets the queue handed out, rows evaluated against the sum of the done counters
+            std::vector<unsigned> dn(G_ * 2), pub(G_);
+            unsigned long long sumDone = 0, sumPub = 0;
+            if (hipMemcpy(dn.data(), done, dn.size() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(pub.data(), done + G_ * 5, pub.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (unsigned v : dn) sumDone += v;
+                for (unsigned v : pub) if (v) sumPub += v - 1u;
+                census = "published " + std::to_string(sumPub) + " tickets " + std::to_string(hq.tail - (unsigned)consumers) + " evaluated " + std::to_string(hq.served) + " sum(done) " + std::to_string(sumDone);
+            } else (void)hipGetLastError();
+        }
+        std::vector<unsigned> all(G_ * 14);                           // live progress[3G] + heartbeats[4G], then the snapshot of both
+        std::string where;
+        if (hipMemcpy(all.data(), done + G_ * 2, all.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            const bool snapped = hq.dbgPop[0] != 0;                    // an evaluator gave up: the snapshot it took before raising the error
+            const unsigned* prog = all.data() + (snapped ? 7 * G_ : 0);
+            const unsigned* hb = prog + 3 * G_;
+            unsigned now = 0;
+            if (snapped) now = prog[2 * G_];
+            else for (size_t g = 0; g < G_; ++g) now = std::max(now, prog[2 * G_ + g]);
+            where = snapped ? " [snapshot at the give-up]" : " [final state]";
+            for (size_t g = 0; g < G_; ++g)
+                if (prog[g]) where += " g" + std::to_string(g) + ":x" + std::to_string((prog[g] >> 4) & 15u) + "p" + std::to_string(prog[g] & 15u) + "/i" + std::to_string(prog[g] >> 8) + "/-" + std::to_string((int)(now - prog[G_ + g]) / 100) + "ms"
+                                      + " w=" + std::to_string(hb[g * 4]) + "," + std::to_string(hb[g * 4 + 1]) + "," + std::to_string(hb[g * 4 + 2]) + "," + std::to_string(hb[g * 4 + 3]);
+        } else (void)hipGetLastError();
         return hm_fail(HM_ERR_STATE, "persistent search gave up waiting (queue error " + std::to_string(hq.error) + "; head " + std::to_string(hq.head) + " tail "
                        + std::to_string(hq.tail) + " producers left " + std::to_string(hq.producers) + " served " + std::to_string(hq.served) + "; search workgroups in/out "
                        + std::to_string(hq.treesIn) + "/" + std::to_string(hq.treesOut) + " of " + std::to_string(sp->nGames) + ", evaluator workgroups in/out "
                        + std::to_string(hq.consIn) + "/" + std::to_string(hq.consOut) + " of " + std::to_string(consumers) + "; first failed wait: game "
                        + std::to_string((int)hq.dbg[0] - 1) + " buffer " + std::to_string(hq.dbg[1]) + " expected " + std::to_string(hq.dbg[2]) + " done " + std::to_string(hq.dbg[3])
-                       + " iteration " + std::to_string(hq.dbg[4]) + " waited ms " + std::to_string(hq.dbg[5]) + ")");
+                       + " iteration " + std::to_string(hq.dbg[4]) + " waited ms " + std::to_string(hq.dbg[5]) + "; evaluator that gave up: ticket "
+                       + std::to_string((int)hq.dbgPop[0] - 1) + " tail " + std::to_string(hq.dbgPop[1]) + "; tickets drawn twice " + std::to_string(hq.dupTickets) + "; census " + census
+                       + "; games:" + where + ")");
+    }
     return 0;
 }
 

@@ -372,10 +372,17 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             s->res.search_kernel_ms += kms;
             return 0;
         }
-        if (!hm_sp_search_not_concurrent(s->sp)) return rc;
-        // the two persistent kernels were run one after the other (e.g. under a counter-collecting profiler): this search and
-        // all later ones of this driver take the host-driven loop
-        s->persistentOff = true;
+        if (hm_sp_search_stalled(s->sp)) {
+            // the evaluator sat idle for 30 ms beside searching games (hm_queue.hpp: IDLE_LIMIT_TICKS): this one search is repeated
+            // from its start on the host-driven loop below — same records — and the next search is a persistent one again
+            s->res.persistent_stalls += 1;
+            if (std::getenv("HM_SEARCH_DEBUG")) std::fprintf(stderr, "[hivemind_amd] stalled persistent search repeated: %s\n", hm_last_error());
+        } else {
+            if (!hm_sp_search_not_concurrent(s->sp)) return rc;
+            // the two persistent kernels were run one after the other (e.g. under a counter-collecting profiler): this search and
+            // all later ones of this driver take the host-driven loop
+            s->persistentOff = true;
+        }
         if (int rc2 = hm_sp_begin_again(s->sp)) return rc2;
     }
     if (native && s->graphState == 0) build_step_graph(s, allRows);

@@ -59,6 +59,7 @@ _SIGS = {
     "hm_sp_search": (_i, [_vp, _vp, _vp, C.POINTER(C.c_double)]),
     "hm_sp_search_consumers": (_i, [_vp]),
     "hm_sp_search_not_concurrent": (_i, [_vp]),
+    "hm_sp_search_stalled": (_i, [_vp]),
     "hm_sp_begin_again": (_i, [_vp]),
     "hm_sp_wait_time": (_i, [_vp, C.POINTER(C.c_double)]),
     "hm_sp_trace_select": (_i, [_i]),

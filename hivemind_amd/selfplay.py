@@ -39,7 +39,8 @@ class SelfPlayResult(C.Structure):
                 ("nodes_visited", C.c_uint64), ("edges_scanned", C.c_uint64),
                 ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double),
                 ("chunks_flushed", C.c_uint64), ("leaf_move_words", C.c_uint64),
-                ("persistent_searches", C.c_uint64), ("search_kernel_ms", C.c_double), ("wait_ms", C.c_double)]
+                ("persistent_searches", C.c_uint64), ("search_kernel_ms", C.c_double), ("wait_ms", C.c_double),
+                ("persistent_stalls", C.c_uint64)]
 
 
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)

@@ -239,6 +239,10 @@ int hm_sp_search(hm_sp* sp, const struct hm_net* net, const struct hm_eval_io* i
  * hm_sp_begin_again then restores the state hm_sp_begin_search had left (same targets, seeds, mask and noise; tree reuse off)
  * so that the lockstep calls can run the search instead. */
 int hm_sp_search_not_concurrent(const hm_sp* sp);
+/* 1 when the last hm_sp_search was given up because its evaluator workgroups had had no row for 30 ms while games were still
+ * searching (observed on MI355X about once in 800 searches with the deployed network; see hm_queue.hpp).  hm_sp_begin_again puts
+ * every slot back to the start of that search; running it again — persistent or lockstep — gives the same result. */
+int hm_sp_search_stalled(const hm_sp* sp);
 int hm_sp_begin_again(hm_sp* sp);
 /* Evaluator workgroups a persistent search of this engine runs (0: not available for this many game slots on this device). */
 int hm_sp_search_consumers(const hm_sp* sp);
@@ -439,6 +443,7 @@ typedef struct hm_selfplay_result {
      * game-iterations), eval_ms the evaluator workgroups' time over eval_rows positions */
     uint64_t persistent_searches;
     double   search_kernel_ms, wait_ms;
+    uint64_t persistent_stalls;          /* persistent searches given up as stalled and repeated on the lockstep loop (hm_sp_search_stalled) */
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,

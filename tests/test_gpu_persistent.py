@@ -126,3 +126,21 @@ def test_selfplay_configs2_full_size_persistent_equals_lockstep(hm, monkeypatch)
     res_l, rec_l, cnt_l = _selfplay(hm, net, **kw)
     assert res_p.persistent_searches > 0 and res_l.persistent_searches == 0
     assert cnt_p == cnt_l and rec_p == rec_l
+
+
+def test_stalled_persistent_search_is_repeated_with_the_same_records(hm, monkeypatch):
+    """Recovery path of a persistent search given up as stalled (hm_queue.hpp: no row published for 30 ms beside searching games;
+    seen on MI355X about once in a few thousand searches with the deployed network): hm_sp_search_stalled -> hm_sp_begin_again ->
+    the same search on the lockstep loop.  The test hook reports every third completed persistent search as stalled; the records
+    must not change, and the following searches are persistent ones again."""
+    net = _net()
+    kw = dict(games=12, nodes=64, seed=5, concurrent_games=12, max_macro_plies=60)
+    res_a, rec_a, cnt_a = _selfplay(hm, net, **kw)
+    assert res_a.persistent_searches > 3 and res_a.persistent_stalls == 0
+    monkeypatch.setenv("HM_SEARCH_FAKE_STALL_EVERY", "3")
+    res_b, rec_b, cnt_b = _selfplay(hm, net, **kw)
+    monkeypatch.delenv("HM_SEARCH_FAKE_STALL_EVERY")
+    assert res_b.persistent_stalls > 0 and res_b.persistent_searches > 0
+    assert res_b.persistent_stalls + res_b.persistent_searches == res_a.persistent_searches
+    assert cnt_b == cnt_a and rec_b == rec_a
+    assert (res_b.samples, res_b.total_nodes) == (res_a.samples, res_a.total_nodes)
