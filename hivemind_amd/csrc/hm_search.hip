@@ -241,6 +241,12 @@ struct G {               // per-wave view of one game's pools
     const int* genAckSeq;
     GenQ* gq;
     int nv, es;                      // nodes visited / edges scanned by this launch's descents (flushed to Game once)
+    // A child reached for the first time gets its position, hash and transposition lookup from the classifier wave (request with
+    // `create` set) while the traversal is already selecting again.  `jPending`: that outcome is still unknown; resolve_create()
+    // waits for it at every step the traversal could not take back.
+    bool jPending, jTakenBack;
+    const int* createSeq;            // requests whose creation step is done
+    const int* createFast;           // 1: the child stayed what the traversal assumed (a fresh leaf), 0: the traversal takes the descent back
     u32* dirty;                      // k_collect with the LDS node mirror: one bit per node the launch may have modified (nullptr otherwise)
 };
 // every node that enters a search path (and every first-reached child before canonicalisation) is marked: those, plus the
@@ -275,6 +281,18 @@ __device__ __forceinline__ void gen_wait(G& s) {
     s.genInflight = -1;
     HB(18);
     PROF_ADD(21, tgw);
+}
+// The creation step of the outstanding request: true when the child is the fresh leaf the traversal took it for (or nothing is
+// outstanding); false when the classifier handed the descent back (a transposition, a pending evaluation, an exhausted pool): the
+// caller unwinds to collect_batch, which undoes what it did on the assumption and continues that descent itself.
+__device__ __forceinline__ bool resolve_create(G& s) {
+    if (!s.jPending) return true;
+    PROF_T(trc);
+    while (__hip_atomic_load(s.createSeq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != s.reqSeq) __builtin_amdgcn_s_sleep(1);
+    s.jPending = false;
+    s.jTakenBack = *s.createFast == 0;
+    PROF_ADD(46, trc);
+    return !s.jTakenBack;
 }
 __device__ __forceinline__ float cpuct_of(const G& s, int v) { return v < s.tabN ? s.ldsCpuct[v] : s.pl->cpuctTab[v]; }
 __device__ __forceinline__ int pw_root_of(const G& s, int v) { return v < s.tabN ? (int)s.ldsPwRoot[v] : (s.g->pwSel ? s.pl->pwRootAlt : s.pl->pwRoot)[v]; }
@@ -438,7 +456,7 @@ struct EdgeScan {
     float visitedPolicySum;  // priors of edges with visits + virtual losses > 0, added in index order
     int visits;              // parent visits incl. virtual visits
 };
-__device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
+__device__ inline bool scan_edges(G& s, const Node& n, EdgeScan& o) {   // false: the outstanding creation was handed back (resolve_create)
     const int lane = threadIdx.x & 63;
     const int limit = n.expanded;
     const Edge* e = edges_of(s, n);
@@ -453,7 +471,10 @@ __device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
         Edge ed;
         ed.child = -2;
         if (i < limit) ed = e[i];
-        if (s.inflight >= 0 && wave_any(ed.child == s.inflight)) svc_wait(s);   // a child whose terminal test is still running
+        if (s.inflight >= 0 && wave_any(ed.child == s.inflight)) {              // a child whose creation / terminal test is still running
+            svc_wait(s);
+            if (!resolve_create(s)) return false;
+        }
         if (i < limit) {
             const int ct = s.nodes[ed.child].type;
             if (base == 0) { o.ed = ed; o.ct = ct; }
@@ -467,6 +488,7 @@ __device__ inline void scan_edges(G& s, const Node& n, EdgeScan& o) {
         o.anyUnvisited |= wave_any(unvisited);
         for (u64 m = __ballot(counted); m; m &= m - 1) o.visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
     }
+    return true;
 }
 __device__ inline bool should_expand_new_child(G& s, const Node& n, const EdgeScan& sc) {
     const bool hasNext = n.more != 0;
@@ -632,6 +654,9 @@ __device__ inline Sel select_child_and_apply_virtual_loss(G& s, int nodeId, cons
         const int child = bestIdx < 64 ? ulane(sc.ed.child, bestIdx) : e[bestIdx].child;
         Node& cn = s.nodes[child];
         bool reserved = false;
+        // stepping onto an expanded, unsolved child only adds a virtual loss (cancel_virtual_losses takes it back); anything else —
+        // a reservation, the end of the descent — waits for the outstanding creation
+        if (!((cn.flags & F_EXPANDED) && cn.type == T_UNSOLVED) && !resolve_create(s)) return {-2, -2, false, pending};
         if (!(cn.flags & F_EXPANDED) && cn.type == T_UNSOLVED) {
             if (cn.flags & F_PENDING) {                        // try_reserve_evaluation failed
                 pending = child;
@@ -768,39 +793,53 @@ __device__ __forceinline__ bool position_child(G& s, const RulesTab& rt, Path& p
     return ok;
 }
 
-// searchthread.cc:818-916.  Returns leaf node id or -1; traj/p updated.
-__device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, bool rootAdv, int rootTeam, bool* reservedOut, u64* unavailMask) {
-    int cur = s.g->root;
-    bool reserved = false;
-    traj[0] = TrajEnt{cur, -1, 0, 0};
-    mark_dirty(s, cur);
-    p.len = 1;
-    p.posNode = -1;
+// searchthread.cc:818-916 as a resumable walk over node ids.  The traversal never holds a position: a child reached for the
+// first time (no position record yet) ends the walk with DESC_CREATE, and the classifier wave gives it its position, hash and
+// transposition lookup (serve_leaf) while the traversal starts its next descent.
+struct Desc {
+    int cur; bool reserved; int len;         // node under examination, whether this descent holds its evaluation reservation, trajectory length
+    int nv, es;                              // nodes visited / edges scanned by this descent (counted once the descent is kept)
+    int parent, idx, child; u32 ma, mb; bool childReserved, widened;   // DESC_CREATE: the edge (parent, idx) -> child to be positioned
+};
+enum : int { DESC_LEAF = 0, DESC_ABORT = 1, DESC_CREATE = 2, DESC_CANCEL = 3 };
+__device__ __forceinline__ void desc_begin(G& s, TrajEnt* traj, Desc& d) {
+    d.cur = s.g->root; d.reserved = false; d.len = 1; d.nv = 0; d.es = 0;
+    traj[0] = TrajEnt{d.cur, -1, 0, 0};
+    mark_dirty(s, d.cur);
+}
+// DESC_LEAF: d.cur is the leaf, d.reserved its reservation.  DESC_ABORT: the selection failed (pending evaluation, exhausted
+// pool): the caller cancels the path's virtual losses.  DESC_CANCEL: the outstanding creation was handed back while this descent
+// was running ahead of it (only virtual losses have been applied: the caller cancels them and repeats the descent later).
+__device__ __forceinline__ int descend(G& s, const RulesTab& rt, TrajEnt* traj, Desc& d, u64* unavailMask) {
+    (void)rt;
     while (true) {
-        if (cur == s.inflight) svc_wait(s);
+        const int cur = d.cur;
+        if (cur == s.inflight) { svc_wait(s); if (!resolve_create(s)) return DESC_CANCEL; }
         if (cur == s.genInflight) gen_wait(s);
         Node n = s.nodes[cur];
-        s.nv++; s.es += n.expanded;
-        if (n.type != T_UNSOLVED) break;
+        d.nv++; d.es += n.expanded;
+        if (n.type != T_UNSOLVED) return resolve_create(s) ? DESC_LEAF : DESC_CANCEL;
         if (!(n.flags & F_EXPANDED)) {
-            if (!reserved) {
-                if (n.flags & F_PENDING) return -1;
+            if (!resolve_create(s)) return DESC_CANCEL;
+            if (!d.reserved) {
+                if (n.flags & F_PENDING) return DESC_ABORT;
                 s.nodes[cur].flags = n.flags | F_PENDING;
-                reserved = true;
+                d.reserved = true;
             }
-            break;
+            return DESC_LEAF;
         }
-        if (p.len >= MAX_TRAJ - 1) { s.g->overflow |= 4; return -1; }
+        if (d.len >= MAX_TRAJ - 1) { if (!resolve_create(s)) return DESC_CANCEL; s.g->overflow |= 4; return DESC_ABORT; }
         int next = -1, childIdx = -1;
         u32 ma = 0, mb = 0;
         bool childReserved = false, widened = false;
         PROF_T(tw);
         EdgeScan sc;
-        scan_edges(s, n, sc);
+        if (!scan_edges(s, n, sc)) return DESC_CANCEL;
         PROF_ADD(29, tw);
         const bool widen = should_expand_new_child(s, n, sc);
         PROF_ADD(1, tw);
         if (widen) {
+            if (!resolve_create(s)) return DESC_CANCEL;           // a popped candidate and a new edge cannot be taken back
             // expand_next_joint_child(nullptr, 0, ..., reserveForSelection = true)  node.h:199-262
             gen_wait(s);                                          // one refill in flight
             GenHdr* gh = gen_of(s, n);
@@ -826,7 +865,7 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
                 const int child = node_alloc(s, n.team ^ 1, n.depth + 1);
                 Node& nn = s.nodes[cur];
                 Edge* slot = child >= 0 ? edge_append(s, nn) : nullptr;
-                if (!slot) return -1;                         // pool exhausted (overflow flagged)
+                if (!slot) return DESC_ABORT;                 // pool exhausted (overflow flagged)
                 s.nodes[child].flags |= F_PENDING;
                 *slot = Edge{child, Q_INIT, Q_INIT, jp, 0, 1, ma, mb, he.iA, he.iB, T_UNSOLVED, 0, 0, 0};
                 nn.vvsum++;
@@ -841,38 +880,32 @@ __device__ __forceinline__ int select_and_expand(G& s, const RulesTab& rt, Path&
             PROF_T(ts);
             const Sel sel = select_child_and_apply_virtual_loss(s, cur, n, sc, unavailMask);
             PROF_ADD(3, ts);
-            if (sel.child < 0 || sel.idx < 0) return -1;
+            if (sel.child == -2) return DESC_CANCEL;
+            if (sel.child < 0 || sel.idx < 0) return resolve_create(s) ? DESC_ABORT : DESC_CANCEL;
             next = sel.child; childIdx = sel.idx; childReserved = sel.reserved;
             if (childIdx < 64) { ma = (u32)ulane((int)sc.ed.moveA, childIdx); mb = (u32)ulane((int)sc.ed.moveB, childIdx); }   // edge held by lane childIdx
             else { const Edge ed = edges_of(s, s.nodes[cur])[childIdx]; ma = ed.moveA; mb = ed.moveB; }
         }
-        // Board::make_moves + canonicalize_child, only for a child that has never been reached (no position, hence no hash)
-        int cr;
-        mark_dirty(s, next);                                   // also when canonicalisation replaces it below (hash, reservation, position)
+        mark_dirty(s, next);                                   // also when canonicalisation replaces it (hash, reservation, position)
         if (s.nodes[next].posOff == 0) {
-            if (!position_child(s, rt, p, cur, next, ma, mb)) return -1;
-            int pend = -1;
-            PROF_T(tc);
-            cr = canonicalize_child(s, rt, p, traj, cur, childIdx, next, childReserved, rootAdv, rootTeam, &pend);
-            PROF_ADD(5, tc);
-            if (cr == 2) return -1;
-        } else {
-            cr = (s.nodes[next].flags & F_EXPANDED) ? 1 : 0;  // canonicalize_child's early outs: hash already set
+            // Board::make_moves + canonicalize_child for a child that has never been reached (no position, hence no hash): the
+            // classifier wave's work.  (The outstanding creation is resolved here: a widening waits for it, and so does the
+            // reservation of an unexpanded child.)
+            d.parent = cur; d.idx = childIdx; d.child = next; d.ma = ma; d.mb = mb; d.childReserved = childReserved; d.widened = widened;
+            return DESC_CREATE;
         }
-        traj[p.len - 1].childIdx = childIdx;
-        mark_dirty(s, next);
-        traj[p.len] = TrajEnt{next, -1, ma, mb};
-        p.len++;
+        const int cr = (s.nodes[next].flags & F_EXPANDED) ? 1 : 0;   // canonicalize_child's early outs: hash already set
+        traj[d.len - 1].childIdx = childIdx;
+        traj[d.len] = TrajEnt{next, -1, ma, mb};
+        d.len++;
         if (widened) {
-            if (cr == 1) { cur = next; reserved = false; continue; }
-            *reservedOut = childReserved;
-            return next;
+            if (cr == 1) { d.cur = next; d.reserved = false; continue; }
+            d.cur = next; d.reserved = childReserved;
+            return resolve_create(s) ? DESC_LEAF : DESC_CANCEL;
         }
-        reserved = childReserved;
-        cur = next;
+        d.reserved = childReserved;
+        d.cur = next;
     }
-    *reservedOut = reserved;
-    return cur;
 }
 
 // ---- leaf planes: wave-cooperative board_to_planes (fp16) for one hm_board in LDS ----------
@@ -964,8 +997,12 @@ struct WaveLds {
     // (two request slots, used alternately: the traversal may post the next leaf while the classifier is still writing the
     // previous leaf's context record and board image)
     TrajEnt trajReq[2][MAX_TRAJ];    // the leaf's path (copied: the traversal reuses `traj` for its next descent)
-    struct Req { int leaf, trajLen, ctxIdx, buf, reserved, first; } req[2];
+    // create != 0: the leaf is a child reached for the first time — the classifier first gives it its position (parent's position +
+    // the joint move), hash and transposition lookup (position_child, canonicalize_child), then classifies it
+    struct Req { int leaf, trajLen, ctxIdx, buf, reserved, first, create, parent, idx; u32 ma, mb; } req[2];
     int reqSeq, typeSeq, ackSeq, svcStop;   // requests posted / terminal test done / finished; svcStop: no more requests in this launch
+    int createSeq;                   // requests whose creation step is done (resolve_create)
+    struct { int fast, cr, next, reserved; } createRes;   // its outcome: fast = the child is the fresh, reserved leaf the traversal assumed; else canonicalize_child's result (cr 3: pool exhausted)
     int reqResult;                   // outcome of the last finished request: 0 network leaf, 1 terminal, 2 dropped (not reserved)
     int svcValid;                    // network leaves of the current batch so far (= plane rows posted)
     int batchLeaf[BATCH];            // leaves of the batch being collected (same-batch collision test)
@@ -991,6 +1028,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
     s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.ackSeq = nullptr; s.typeSeq = nullptr;
     s.genInflight = -1; s.genReqSeq = 0; s.genAckSeq = nullptr; s.gq = nullptr; s.nv = 0; s.es = 0; s.dirty = nullptr;
+    s.jPending = false; s.jTakenBack = false; s.createSeq = nullptr; s.createFast = nullptr;
     return s;
 }
 
@@ -1221,10 +1259,40 @@ template <bool WT = false>
 __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L, int rootTeam, bool rootAdv, int seq, const PubCtx* pc = nullptr) {
     const int lane = threadIdx.x & 63;
     const WaveLds::Req rq = L.req[seq & 1];
-    const TrajEnt* trajReq = L.trajReq[seq & 1];
+    TrajEnt* trajReq = L.trajReq[seq & 1];
     const int leaf = rq.leaf, len = rq.trajLen, buf = rq.buf, slot = rq.ctxIdx;
     const bool reserved = rq.reserved != 0;
     const int valid = rq.first ? 0 : L.svcValid;
+    PROF_T(tsv);
+    Path p;
+    if (rq.create) {
+        // The child's position = the parent's cached position + the edge's joint move (Board::make_moves), then its hash and the
+        // transposition lookup (canonicalize_child, searchthread.cc:741-806) — on this wave, while the traversal selects again.
+        // The traversal assumed the common outcome: the child stays itself, fresh and reserved.  Anything else (the edge now
+        // points to a known node, a pending evaluation, an exhausted pool) goes back to it: it undoes what it did on the
+        // assumption and continues this descent itself (collect_batch).
+        PROF_T(tcr);
+        int next = leaf, pend = -1;
+        bool childReserved = reserved;
+        int cr = 3;
+        p.len = len - 1;                                       // the path down to the parent (canonicalize_child's ancestor test)
+        p.posNode = -1;
+        if (position_child(s, rt, p, rq.parent, leaf, rq.ma, rq.mb))
+            cr = canonicalize_child(s, rt, p, trajReq, rq.parent, rq.idx, next, childReserved, rootAdv, rootTeam, &pend);
+        const bool fast = cr == 0 && next == leaf && childReserved == reserved;
+        if (lane == 0) { L.createRes.fast = fast ? 1 : 0; L.createRes.cr = cr; L.createRes.next = next; L.createRes.reserved = childReserved ? 1 : 0; }
+        wave_fence();
+        if (lane == 0) __hip_atomic_store(&L.createSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PROF_ADD_T(47, tcr, 64);
+        if (!fast) {                                           // nothing is classified: the request ends here
+            if (lane == 0) L.reqResult = 3;
+            wave_fence();
+            if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+    } else {
+        path_load(s, p, leaf);                                 // the leaf's joint position (cached at first reach)
+    }
     Ctx ctx;
     ctx.leaf = leaf; ctx.trajLen = len; ctx.reserved = reserved;
     ctx.team = s.nodes[leaf].team;
@@ -1232,10 +1300,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     ctx.terminal = 0; ctx.termValue = 0.0f; ctx.leafHash = 0;
     const int searchPly = len - 1;
     const float drawValue = ctx.team == rootTeam ? -s.prm->drawContempt : s.prm->drawContempt;
-    PROF_T(tsv);
-    Path p;
-    path_load(s, p, leaf);                                     // the leaf's joint position (cached at first reach)
-    path_rebuild_history(s, trajReq, len);                   // and the repetition keys of its path
+    path_rebuild_history(s, trajReq, len);                   // the repetition keys of its path
     PROF_ADD_T(15, tsv, 64);
     // The plane-writer wave starts on this leaf now, into row `valid`, while the terminal test below runs: a leaf that turns out
     // terminal (or is dropped) simply leaves `valid` where it is and the next network leaf overwrites the row (posts are served
@@ -1305,40 +1370,102 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
     const int lane = threadIdx.x & 63;
     int nctx = 0, attempts = 0;
     bool posted = false;
-    Path p;
+    Desc d;
+    bool running = false;        // d is a descent in progress (being repeated after a cancel, or continued after a hand-back)
+    // the descent whose creation request is outstanding (s.jPending), as it stood before the request was posted on the
+    // assumption "fresh, reserved leaf": what a hand-back has to restore
+    Desc dj;
+    int jSlot = 0, jNctx = 0, jMaxDepth = 0;
+    bool jPosted = false;
     TRACE_SEQ();
-    while (nctx < BATCH && attempts < BATCH * 2) {
-        attempts++;
-        HB(100 + attempts);
-        PROF_T(t0);
-        bool reserved = false;
-        const int leaf = select_and_expand(s, rt, p, L.traj, rootAdv, rootTeam, &reserved, L.unavail);
-        PROF_ADD(0, t0);
-        if (leaf < 0) {
-            TRACE_EV(1, p.len, 0);
+    s.jPending = false; s.jTakenBack = false;
+    for (;;) {
+        int rc;
+        if (s.jTakenBack) {
+            // ---- the classifier handed descent j back (canonicalize_child changed the edge, met a pending evaluation, or a pool is
+            // exhausted).  Undo the descent that ran ahead (virtual losses only) and j's bookkeeping, then go on exactly where
+            // select_and_expand stands after canonicalize_child (searchthread.cc:846-916).
+            s.jTakenBack = false;
+            if (running) { cancel_virtual_losses(s, L.traj, d.len); attempts--; running = false; }
+            svc_join(s);                                           // the request has ended (nothing was classified)
+            s.nv -= dj.nv + (dj.widened ? 0 : 1); s.es -= dj.es;
+            nctx = jNctx; posted = jPosted; s.g->maxDepth = jMaxDepth;
+            for (int i = lane; i < dj.len; i += 64) L.traj[i] = L.trajReq[jSlot][i];
+            wave_fence();
+            d = dj;
+            const int cr = L.createRes.cr, next = L.createRes.next;
+            const bool childReserved = L.createRes.reserved != 0;
+            if (cr >= 2) {                                         // pending evaluation behind the transposition (its virtual loss is already removed) / pool exhausted
+                L.traj[d.len - 1].childIdx = -1;                   // as select_and_expand leaves it when it gives up here
+                wave_fence();
+                rc = DESC_ABORT;
+            }
+            else {
+                L.traj[d.len - 1].childIdx = d.idx;
+                mark_dirty(s, next);
+                L.traj[d.len] = TrajEnt{next, -1, d.ma, d.mb};
+                d.len++;
+                d.cur = next;
+                if (d.widened && cr == 0) { d.reserved = childReserved; rc = DESC_LEAF; }
+                else { d.reserved = d.widened ? false : childReserved; rc = descend(s, rt, L.traj, d, L.unavail); }
+            }
+        } else {
+            if (!running) {
+                if (!(nctx < BATCH && attempts < BATCH * 2)) {
+                    if (resolve_create(s)) break;                  // the batch stands once the last creation went the assumed way
+                    continue;
+                }
+                attempts++;
+                HB(100 + attempts);
+                desc_begin(s, L.traj, d);
+                running = true;
+            }
+            PROF_T(t0);
+            rc = descend(s, rt, L.traj, d, L.unavail);
+            PROF_ADD(0, t0);
+        }
+        if (rc == DESC_CANCEL) continue;                           // s.jTakenBack is set: the branch above takes over
+        running = false;
+        s.nv += d.nv; s.es += d.es;
+        if (rc == DESC_ABORT) {
+            TRACE_EV(1, d.len, 0);
             s.g->reservationCollisions++;
-            cancel_virtual_losses(s, L.traj, p.len);
+            cancel_virtual_losses(s, L.traj, d.len);
             continue;
         }
-        bool collision = false;
-        for (int i = 0; i < nctx; ++i) collision |= L.batchLeaf[i] == leaf;
-        if (collision) {
-            TRACE_EV(2, p.len, 0);
-            s.g->sameBatchCollisions++;
-            if (leaf == s.inflight) svc_wait(s);
-            if (reserved) s.nodes[leaf].flags &= ~F_PENDING;
-            cancel_virtual_losses(s, L.traj, p.len);
-            continue;
+        const bool create = rc == DESC_CREATE;
+        int leaf = d.cur;
+        bool reserved = d.reserved;
+        if (create) {
+            // assume the common outcome: the child stays itself — a fresh, reserved leaf that cannot collide with this batch's leaves
+            dj = d; jNctx = nctx; jPosted = posted; jMaxDepth = s.g->maxDepth;
+            L.traj[d.len - 1].childIdx = d.idx;
+            L.traj[d.len] = TrajEnt{d.child, -1, d.ma, d.mb};
+            d.len++;
+            leaf = d.child; reserved = d.childReserved;
+            if (!d.widened) s.nv++;                                // the visit of the leaf itself (the walk's next step)
+            if (!reserved) { if (lane == 0) atomicOr(&s.g->overflow, 256); }   // cannot happen: a child without a position is unexpanded and unsolved, hence reserved by its selection
+        } else {
+            bool collision = false;
+            for (int i = 0; i < nctx; ++i) collision |= L.batchLeaf[i] == leaf;
+            if (collision) {
+                TRACE_EV(2, d.len, 0);
+                s.g->sameBatchCollisions++;
+                if (leaf == s.inflight) svc_wait(s);
+                if (reserved) s.nodes[leaf].flags &= ~F_PENDING;
+                cancel_virtual_losses(s, L.traj, d.len);
+                continue;
+            }
         }
-        const int searchPly = p.len - 1;
+        const int searchPly = d.len - 1;
         if (searchPly > s.g->maxDepth) s.g->maxDepth = searchPly;
         if (leaf == s.inflight) svc_wait(s);
-        const uint8_t solved = s.nodes[leaf].type;
+        const uint8_t solved = create ? (uint8_t)T_UNSOLVED : s.nodes[leaf].type;
         bool keep = true;
         if (solved != T_UNSOLVED) {
-            TRACE_EV(3, p.len, solved);
+            TRACE_EV(3, d.len, solved);
             Ctx ctx;
-            ctx.leaf = leaf; ctx.trajLen = p.len; ctx.reserved = reserved;
+            ctx.leaf = leaf; ctx.trajLen = d.len; ctx.reserved = reserved;
             ctx.team = s.nodes[leaf].team;
             ctx.sit = ((ctx.team == rootTeam) == rootAdv) ? 1 : 0;
             ctx.terminal = 1; ctx.leafHash = 0;
@@ -1346,26 +1473,28 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             ctx.termValue = solved == T_WIN ? 1.0f : solved == T_LOSS ? -1.0f : drawValue;
             s.ctx[buf * BATCH + nctx] = ctx;
             TrajEnt* dst = s.traj + (size_t)(buf * BATCH + nctx) * MAX_TRAJ;
-            for (int i = lane; i < p.len; i += 64) dst[i] = L.traj[i];
+            for (int i = lane; i < d.len; i += 64) dst[i] = L.traj[i];
             wave_fence();
         } else {
             PROF_T(tk);
             svc_wait(s);                                           // one terminal test in flight
             svc_join(s, 1);                                        // and the request slot about to be reused is free
             const int rslot = (s.reqSeq + 1) & 1;
-            for (int i = lane; i < p.len; i += 64) L.trajReq[rslot][i] = L.traj[i];
-            if (lane == 0) L.req[rslot] = WaveLds::Req{leaf, p.len, nctx, buf, reserved ? 1 : 0, posted ? 0 : 1};
+            for (int i = lane; i < d.len; i += 64) L.trajReq[rslot][i] = L.traj[i];
+            if (lane == 0) L.req[rslot] = WaveLds::Req{leaf, d.len, nctx, buf, reserved ? 1 : 0, posted ? 0 : 1, create ? 1 : 0, d.parent, d.idx, d.ma, d.mb};
             wave_fence();
             s.reqSeq++;
             if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             s.inflight = leaf; s.svcBusy = true;
             posted = true;
+            if (create) { s.jPending = true; jSlot = rslot; }
             if (!reserved) {                                       // rare: whether the context is kept depends on the terminal test
                 svc_wait(s);
+                if (s.jPending && !resolve_create(s)) continue;    // (not reachable: a creation request is always reserved)
                 if (L.reqResult == 2) {
-                    TRACE_EV(5, p.len, 0);
+                    TRACE_EV(5, d.len, 0);
                     s.g->reservationCollisions++;
-                    cancel_virtual_losses(s, L.traj, p.len);
+                    cancel_virtual_losses(s, L.traj, d.len);
                     keep = false;
                 }
             }
@@ -1646,7 +1775,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         const int* pwn = alt ? pl.pwNodeAlt : pl.pwNode;
         for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
     }
-    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
+    if (threadIdx.x == 0) { L.posted = 0; L.done = 0; L.listWords = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.createSeq = 0; L.svcStop = 0; L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0; }
     if (threadIdx.x < LDS_DIRTY_BITS / 32) s_dirty[threadIdx.x] = 0;
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
@@ -1666,7 +1795,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     PROF_ADD(9, ta);
     const int wave = threadIdx.x >> 6;
     if (wave == 0) {
-        s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq;
+        s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast;
         s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq;
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
         if (threadIdx.x == 0) {
@@ -1800,7 +1929,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     }
     s.g = &s_game;
     s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
-    if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
+    if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
     const int rootTeam = s_game.team;
     const bool rootAdv = s_game.adv != 0;
     const int rowBase = g * BATCH;
@@ -1869,7 +1998,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             s_ctl.first = first ? 1 : 0;
             s_ctl.buf = first ? 0 : 1 - s_game.pending;
             // hand-off state of one collect phase
-            L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.svcStop = 0;
+            L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.createSeq = 0; L.svcStop = 0;
             L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
             for (int i = 0; i < BATCH; ++i) L.postReady[i] = 0;
             // the root's own expansion (first batch of a search from a fresh root) mixes Dirichlet noise into the priors

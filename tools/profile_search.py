@@ -37,7 +37,7 @@ names = ["select_and_expand(total)", "should_expand_new_child", "gen_next", "sel
          "(clock ticks)", "(clock ticks)",
          "k_search: collect phase", "k_search: collect_batch (wave 0)", "k_search: publish", "k_search: wait for evaluation", "k_search: process phase",
          "k_search: backups (wave 0)", "k_search: control", "k_search: drain + barrier", "expand: gather + softmax (wave 1)", "expand: sort + store (wave 1)",
-         "expand: frontier + first child (wave 1)", "k_search: expansions (wave 1)", "-", "k_search: iteration tail"]
+         "expand: frontier + first child (wave 1)", "k_search: expansions (wave 1)", "-", "k_search: iteration tail", "wait: creation outcome (resolve_create)", "classifier wave: creation step"]
 it = res.search_iterations
 if res.persistent_searches:
     it = max(1, int(buf[64 + 32]))          # game slot 0 only: its own iterations
