@@ -129,8 +129,8 @@ def _pmc_traffic(path):
     return out
 
 
-PMC_SELFPLAY = "profiles/r02_selfplay64_pmc_hbm.json"
-PMC_PLANES = "profiles/r02_planes_pmc_hbm.json"
+PMC_SELFPLAY = "profiles/r03_selfplay64_pmc_hbm.json"
+PMC_PLANES = "profiles/r03_planes_pmc_hbm.json"
 
 
 def launch_ranks(n, argv):
@@ -300,7 +300,8 @@ def main():
         for w in range(args.warmup):
             one_run(1000 + w)
         tot = dict(samples=0, nodes=0, eval_rows=0, iters=0, collect_ms=0.0, eval_ms=0.0, process_ms=0.0, nv=0, es=0, games=0, bytes=0, lw=0,
-                   searches=0, search_kernel_ms=0.0, wait_ms=0.0, search_s=0.0, prologue_s=0.0, raw_s=0.0, seconds=0.0, positions=0)
+                   searches=0, search_kernel_ms=0.0, wait_ms=0.0, search_s=0.0, prologue_s=0.0, raw_s=0.0, seconds=0.0, positions=0,
+                   stalls=0, tt_hits=0, tt_inserts=0)
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -312,6 +313,7 @@ def main():
             tot["searches"] += res.persistent_searches; tot["search_kernel_ms"] += res.search_kernel_ms; tot["wait_ms"] += res.wait_ms
             tot["search_s"] += res.search_seconds; tot["prologue_s"] += res.prologue_seconds; tot["raw_s"] += res.raw_seconds
             tot["seconds"] += res.seconds; tot["positions"] += res.searched_positions
+            tot["stalls"] += res.persistent_stalls; tot["tt_hits"] += res.tt_hits; tot["tt_inserts"] += res.tt_inserts
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         samples = sum_over_ranks(tot["samples"])
@@ -389,6 +391,9 @@ def main():
                              "leg_ms_per_iteration": legs,
                              "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9,
                              "persistent_searches": tot["searches"], "search_kernel_ms_total": tot["search_kernel_ms"], "wait_ms_total": tot["wait_ms"],
+                             "persistent_searches_repeated_after_a_stall": tot["stalls"],
+                             "transposition_table": {"lookups_that_hit": tot["tt_hits"], "inserts": tot["tt_inserts"],
+                                                     "hit_rate": tot["tt_hits"] / max(tot["tt_hits"] + tot["tt_inserts"], 1)},
                              "wall_split_s": {"run": tot["seconds"], "search": tot["search_s"], "prologue": tot["prologue_s"], "raw_policy": tot["raw_s"]}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_selfplay_baseline(model, args.nodes)

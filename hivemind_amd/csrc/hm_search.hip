@@ -127,6 +127,7 @@ struct Game {
     float alpha, eps;
     u64 noiseSeed, rootHash;
     int sameBatchCollisions, reservationCollisions, evalRows, overflow, maxDepth, ttCount;
+    int ttHits;                         // lookups that found their position in the table (transposition_table.h:83-103), this search
     int nodesVisited, edgesScanned;     // traversal traffic counters (roofline accounting)
     int fresh;                          // batch `pending` was collected this iteration: its planes are in NEXT, not yet evaluated
     int listWords;                      // leaf move-list words written by the helper wave (traffic accounting)
@@ -333,7 +334,7 @@ __device__ inline int tt_insert_or_get(G& s, u64 hash, int node) {
             s.ttKeys[i] = hash; s.ttVals[i] = node; s.g->ttCount++;
             return node;
         }
-        if (s.ttKeys[i] == hash) return v;
+        if (s.ttKeys[i] == hash) { s.g->ttHits++; return v; }
         i = (i + 1) & (cap - 1);
     }
     return node;
@@ -2217,7 +2218,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     // The pool itself is reset below, once it is known that the previous search's tree is not carried over (tree reuse).
     const int prevRoot = gm.reuseMode ? gm.lastRootP1 - 1 : -1;
     gm.reusedVisits = -1;
-    gm.ttCount = 0; gm.nodesSearched = 0; gm.pending = -1;
+    gm.ttCount = 0; gm.ttHits = 0; gm.nodesSearched = 0; gm.pending = -1;
     gm.ctxCount[0] = gm.ctxCount[1] = gm.validCount[0] = gm.validCount[1] = 0;
     gm.sameBatchCollisions = gm.reservationCollisions = gm.evalRows = gm.overflow = gm.maxDepth = 0;
     gm.nodesVisited = gm.edgesScanned = 0; gm.fresh = 0; gm.listWords = 0;
@@ -2423,6 +2424,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         int* inf = o.info + (size_t)g * HM_SP_INFO_INTS;
         inf[12] = gm.root >= 0 ? best_move_index(s, s.nodes[gm.root], prm.qVetoDelta, prm.qValueWeight) : -1;
         inf[13] = gm.listWords; inf[14] = inf[15] = 0;
+        inf[18] = gm.ttHits; inf[19] = gm.ttCount;
         if (inf[12] >= 0 && gm.root >= 0 && (s.nodes[gm.root].flags & F_EXPANDED) && inf[12] < s.nodes[gm.root].expanded) {
             const Node& bc = s.nodes[edges_of(s, s.nodes[gm.root])[inf[12]].child];    // for format_uci_score (agent.cc:48-78)
             inf[14] = bc.type; inf[15] = bc.endInPly;
@@ -2430,7 +2432,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Pools pl, Params prm, RootOut
         inf[0] = gm.status; inf[1] = gm.nodesSearched; inf[2] = gm.evalRows; inf[3] = gm.sameBatchCollisions; inf[4] = gm.reservationCollisions;
         inf[5] = gm.nodeCount; inf[6] = gm.root >= 0 ? s.nodes[gm.root].type : -1; inf[7] = gm.root >= 0 ? s.nodes[gm.root].visits : 0;
         inf[8] = gm.overflow; inf[9] = gm.maxDepth; inf[10] = gm.nodesVisited; inf[11] = gm.edgesScanned;
-        inf[16] = gm.reusedVisits; inf[17] = gm.targetNodes; inf[18] = inf[19] = 0;
+        inf[16] = gm.reusedVisits; inf[17] = gm.targetNodes;
     }
 }
 

@@ -765,6 +765,8 @@ static int selfplay_run_impl(hm_selfplay* s) {
             s->res.nodes_visited += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 10];
             s->res.edges_scanned += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 11];
             s->res.leaf_move_words += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 13];
+            s->res.tt_hits += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 18];
+            s->res.tt_inserts += (uint64_t)info[(size_t)g * HM_SP_INFO_INTS + 19];
             const int n = counts[g];
             if (n == 0) { sl.winner = sl.team == HM_WHITE ? 1 : 0; sl.termination = 4; finish_game(s, sl); continue; }
             const hm_move* ea = mA.data() + (size_t)g * E;

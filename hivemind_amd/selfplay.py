@@ -40,7 +40,7 @@ class SelfPlayResult(C.Structure):
                 ("search_seconds", C.c_double), ("prologue_seconds", C.c_double), ("raw_seconds", C.c_double),
                 ("chunks_flushed", C.c_uint64), ("leaf_move_words", C.c_uint64),
                 ("persistent_searches", C.c_uint64), ("search_kernel_ms", C.c_double), ("wait_ms", C.c_double),
-                ("persistent_stalls", C.c_uint64)]
+                ("persistent_stalls", C.c_uint64), ("tt_hits", C.c_uint64), ("tt_inserts", C.c_uint64)]
 
 
 EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)

@@ -260,7 +260,8 @@ int hm_sp_active(hm_sp* sp, int* active);
  * Q_VETO_DELTA 0.4 / Q_VALUE_WEIGHT 1.0, then the fallbacks of agent.cc:872-886), [13] = leaf move-list words written
  * (traffic accounting), [14] / [15] = solver type (0 unsolved, 1 win, 2 loss, 3 draw — from the child's side) and endInPly of that
  * action's child node (format_uci_score, agent.cc:48-78), [16] = visits of the root recovered by tree reuse (-1 = fresh root),
- * [17] = node budget in force (hm_sp_set_tree_reuse), [18..19] reserved. */
+ * [17] = node budget in force (hm_sp_set_tree_reuse), [18] / [19] = transposition-table lookups of this search that found their
+ * position / entries inserted (TranspositionTable::insertOrGet, transposition_table.h:83-103). */
 #define HM_SP_INFO_INTS 20
 int hm_sp_max_edges(const hm_sp* sp);
 int hm_sp_root_stats(hm_sp* sp, int* counts, hm_move* move_a, hm_move* move_b, int* visits, float* q, float* prior,
@@ -444,6 +445,7 @@ typedef struct hm_selfplay_result {
     uint64_t persistent_searches;
     double   search_kernel_ms, wait_ms;
     uint64_t persistent_stalls;          /* persistent searches given up as stalled and repeated on the lockstep loop (hm_sp_search_stalled) */
+    uint64_t tt_hits, tt_inserts;        /* transposition-table lookups that found their position / inserted it, over all searches */
 } hm_selfplay_result;
 
 int hm_selfplay_create(const hm_selfplay_config* cfg, const hm_search_config* search_cfg, const hm_eval_io* io,

@@ -184,15 +184,16 @@ def test_selfplay_full_size_config2_sampled_games_match_oracle(hm, tmp_path):
 
 def test_selfplay_nodes1600_config4_sampled_games_match_oracle(hm, tmp_path):
     """BASELINE configs[4]'s search shape — nodes 1600, transposition-sharing MCGS, Dirichlet root noise (all defaults) — over
-    whole games: two sampled games of a 12-game run equal the CPU restatement byte for byte."""
-    kw = dict(games=12, nodes=1600, seed=404, concurrent_games=12, max_macro_plies=60)
+    whole games: sampled games of a 64-game run (the per-GPU game count of the configuration) equal the CPU restatement byte
+    for byte."""
+    kw = dict(games=64, nodes=1600, seed=404, concurrent_games=64, max_macro_plies=60)
     sp = hm.SelfPlay(hm.default_selfplay_config(**kw), DeviceHashNet(hm))
     res = sp.run()
     rec, cnt = sp.records()
     sp.close()
-    assert res.games == 12
+    assert res.games == 64
     got = _split_by_game(hm, tmp_path, rec, cnt, "n1600.hvm")
     ora = O.SelfPlayOracle(O.selfplay_cfg(**kw), 1, 1)
-    for g in (3, 11):
+    for g in (3, 41):
         want, info, _ = ora.game(g)
         assert got.get(g, b"") == want, (g, info, len(got.get(g, b"")), len(want))
