@@ -3165,12 +3165,24 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     // queues and two of them may share one (the second kernel would then wait for the first to end — which waits for the second).
     // Streams created with a CU mask own their queue; the mask enables every CU.
     if (!sp->sTree) {
+        const char* plain = std::getenv("HM_SEARCH_PLAIN_STREAMS");
+        if (plain && plain[0] != '0') {
+            // experiment (the stall): ordinary streams of different priority instead of CU-masked ones — streams of
+            // different priorities never share a hardware queue
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&sp->sTree, hipStreamDefault, hi) != hipSuccess || hipStreamCreateWithPriority(&sp->sNet, hipStreamDefault, lo) != hipSuccess) {
+                (void)hipGetLastError();
+                return hm_fail(HM_ERR_NO_DEVICE, "hipStreamCreateWithPriority failed");
+            }
+        } else {
         const int words = (sp->numCUs + 31) / 32;
         std::vector<uint32_t> all((size_t)words, 0xffffffffu);
         if (sp->numCUs % 32) all[(size_t)words - 1] = (1u << (sp->numCUs % 32)) - 1u;
         if (hipExtStreamCreateWithCUMask(&sp->sTree, (uint32_t)words, all.data()) != hipSuccess || hipExtStreamCreateWithCUMask(&sp->sNet, (uint32_t)words, all.data()) != hipSuccess) {
             (void)hipGetLastError();
             return hm_fail(HM_ERR_NO_DEVICE, "hipExtStreamCreateWithCUMask failed (persistent search needs two hardware queues)");
+        }
         }
     }
     hipStream_t sT = sp->sTree, sN = sp->sNet;
