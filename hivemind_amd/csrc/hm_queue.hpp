@@ -59,6 +59,9 @@ struct SrvQueue {                            // one per search engine; zeroed (w
 static_assert(sizeof(SrvQueue) % 16 == 0, "zeroed as one block of 16-byte multiples");
 
 #define HMQ_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef HMQ_IDLE_SLEEP
+#define HMQ_IDLE_SLEEP 8              // s_sleep argument (x 64 clocks) between two polls of an idle evaluator workgroup
+#endif
 // Every word two workgroups share is accessed as GLOBAL memory (address space 1: global_* instructions), never through a generic
 // pointer (flat_*: the queue pointer often comes out of LDS or a by-value struct, where the compiler cannot infer the address space).
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -114,7 +117,7 @@ __device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
     for (unsigned spins = 0;; ++spins) {
         const u64q v = __hip_atomic_load(G64(slot), HMQ_RLX);
         if ((unsigned)(v >> 32) == t + 1) return (unsigned)v;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(HMQ_IDLE_SLEEP);
         if ((spins & 255u) == 255u) {
             if (__hip_atomic_load(G32(&q->error), HMQ_RLX)) return IT_POISON;
             const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
