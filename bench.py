@@ -113,10 +113,12 @@ def _pmc_traffic(path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary
     best = {}
+    global _PMC_ALGO
     try:
         prof = json.load(open(os.path.join(ROOT, path)))
         if not isinstance(prof, dict) or prof.get("source_sha256") != pmc_summary.source_hash():
             return {}
+        _PMC_ALGO[path] = prof.get("algorithmic_bytes_per_launch_same_phase")
         for r in prof["rows"]:
             key = (r["kernel"], r["counter"])
             if key not in best or r["launches"] > best[key]["launches"]:
@@ -129,6 +131,7 @@ def _pmc_traffic(path):
     return out
 
 
+_PMC_ALGO = {}                 # per summary file: algorithmic bytes per launch of the profiled command's own phase (tools/run_selfplay.py)
 PMC_SELFPLAY = "profiles/r03_selfplay64_pmc_hbm.json"
 PMC_PLANES = "profiles/r03_planes_pmc_hbm.json"
 
@@ -354,7 +357,15 @@ def main():
                         "note": "launch duration = the search's; the evaluator idles whenever the games have no batch for it",
                         "traffic_source": roof_tree["traffic_source"]}
             if pmc:
-                extra["lockstep_pmc_traffic"] = {"source": PMC_SELFPLAY, "bytes_per_launch": pmc}
+                same = _PMC_ALGO.get(PMC_SELFPLAY) or {}
+                cmp_ = {}
+                for key in ("k_collect", "rise_forward"):
+                    hit = [k for k in pmc if key in k]
+                    if hit and same.get(key):
+                        tr = sum(pmc[k] for k in hit)
+                        cmp_[key] = {"traffic_bytes_per_launch": tr, "algorithmic_bytes_per_launch_same_phase": same[key], "ratio": tr / same[key]}
+                extra["lockstep_pmc_traffic"] = {"source": PMC_SELFPLAY, "bytes_per_launch": pmc, "same_phase": cmp_,
+                                                 "note": "counters and algorithmic bytes both over the profiled command (first 30 macro-plies, all games alive, lockstep kernels)"}
         else:
             legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
                     "k_process (expand+backup)": tot["process_ms"] / it}
@@ -380,6 +391,10 @@ def main():
                 hit = [k for k in pmc if key in k]
                 if hit:
                     r_["traffic"] = sum(pmc[k] for k in hit)
+                    same = (_PMC_ALGO.get(PMC_SELFPLAY) or {}).get("k_collect" if key == "k_collect" else "rise_forward")
+                    if same:                   # both numbers over the profiled command's own phase (the run's average launch is thinner)
+                        r_["algorithmic_bytes_per_launch_same_phase"] = same
+                        r_["traffic_over_algorithmic_same_phase"] = r_["traffic"] / same
                     r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
                 else:
                     r_["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"

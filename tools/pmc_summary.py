@@ -50,6 +50,7 @@ def main():
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
+    ap.add_argument("--algo-log", default=None, help="stdout of the profiled command (tools/run_selfplay.py prints ALGO_BYTES_PER_LAUNCH {...}): algorithmic bytes per launch of the same phase")
     ap.add_argument("--kernels", default="k_collect,k_process,k_begin,rise_forward,encode_planes_kernel,perft", help="substrings to keep")
     a = ap.parse_args()
     keep = [s for s in a.kernels.split(",") if s]
@@ -74,7 +75,13 @@ def main():
         dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "hivemind_amd/csrc", "include"], text=True).strip())
     except Exception:
         sha, dirty = None, None
-    json.dump(dict(command=a.command, git_commit=sha, git_dirty_sources=dirty, source_sha256=source_hash(), rows=rows), open(a.out, "w"), indent=1)
+    algo = None
+    if a.algo_log and os.path.exists(a.algo_log):
+        for line in open(a.algo_log, errors="replace"):
+            if line.startswith("ALGO_BYTES_PER_LAUNCH "):
+                algo = json.loads(line[len("ALGO_BYTES_PER_LAUNCH "):])
+    json.dump(dict(command=a.command, git_commit=sha, git_dirty_sources=dirty, source_sha256=source_hash(), rows=rows,
+                   algorithmic_bytes_per_launch_same_phase=algo), open(a.out, "w"), indent=1)
     print(f"wrote {len(rows)} rows to {a.out}")
 
 

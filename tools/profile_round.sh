@@ -9,6 +9,8 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout -k 10 500 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench.err
+timeout -k 10 300 python3 bench.py --model full --steps 2 --warmup 1 --no-extra --no-cpu-baseline > gpurun_out/bench_line_full_net.json 2> gpurun_out/bench_full.err
+timeout -k 10 300 python3 bench.py --nodes 1600 --steps 1 --warmup 0 --no-extra --no-cpu-baseline > gpurun_out/bench_line_nodes1600.json 2> gpurun_out/bench_1600.err
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/ks -o ks -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $ROOT/gpurun_out/ks.log 2>&1
 SP="python3 $ROOT/tools/run_selfplay.py --games 64 --nodes 400 --concurrent 64 --max-macro-plies 30 --out /tmp/sp_out"

@@ -39,6 +39,16 @@ samples = hm.read_hvm4(path)
 for s in samples:
     for p in (s["policy_a"], s["policy_b"]):
         assert abs(float(p["prob"].sum()) - 1.0) < 1e-4
+# algorithmic HBM bytes per launch of the lockstep kernels over THIS run (the formula of bench.py's lockstep roofline): what a PMC
+# pass of this command is compared with (tools/pmc_summary.py --algo-log)
+it_ = max(res.search_iterations, 1)
+algo = None
+if not res.persistent_searches:
+    rows_ = res.eval_rows / it_
+    algo = {"k_collect": (res.nodes_visited * (64 + 104) + res.edges_scanned * 40 + res.leaf_move_words * 4) / it_ + rows_ * 9472,
+            "rise_forward": rows_ * (9472 + 2 * 9344 + 10) + 2.0e6,          # planes in, both policy planes + value heads out, the packed weights once
+            "launches": it_, "rows_per_launch": rows_}
+print("ALGO_BYTES_PER_LAUNCH " + json.dumps(algo))
 print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searched_positions, nodes=res.total_nodes,
                       eval_rows=res.eval_rows, eval_batches=res.eval_batches, iters=res.search_iterations, raw=res.raw_plies,
                       seconds=res.seconds, wall=dt, positions_per_s=res.samples / res.seconds, nodes_per_s=res.total_nodes / res.seconds,
