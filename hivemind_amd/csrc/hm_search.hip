@@ -1367,7 +1367,18 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     PROF_ADD_T(23, tsv, 64);
 }
 
-__device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv) {
+// the end of a collect phase: every request served, the generator idle, the batch's counts final
+__device__ __forceinline__ void collect_finish(G& s, WaveLds& L, int buf, int nctx, bool posted) {
+    svc_join(s);
+    gen_wait(s);
+    const int valid = posted ? L.svcValid : 0;
+    s.g->ctxCount[buf] = nctx;
+    s.g->validCount[buf] = valid;
+    s.g->evalRows += valid;
+}
+// tail != nullptr: return once the last request is posted and its creation step has gone the assumed way — {contexts, posted} in
+// tail[0..1], collect_finish is the caller's (k_search runs the backups of the batch before while the classifier finishes this one)
+__device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, int* tail = nullptr) {
     const int lane = threadIdx.x & 63;
     int nctx = 0, attempts = 0;
     bool posted = false;
@@ -1507,12 +1518,8 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             nctx++;
         }
     }
-    svc_join(s);
-    gen_wait(s);
-    const int valid = posted ? L.svcValid : 0;
-    s.g->ctxCount[buf] = nctx;
-    s.g->validCount[buf] = valid;
-    s.g->evalRows += valid;
+    if (tail) { tail[0] = nctx; tail[1] = posted ? 1 : 0; return; }
+    collect_finish(s, L, buf, nctx, posted);
 }
 
 // =======================================================================================
@@ -1879,7 +1886,7 @@ struct SearchIo {
     const uint8_t* netSel;                   // per game: evaluator index of its items (nullptr: 0)
     int ldsNodes;                            // the node pool fits in LDS beside k_search's static LDS
 };
-struct SearchCtl { int action, buf, first, ok; };
+struct SearchCtl { int action, buf, first, ok, nctx; };   // nctx: contexts of the batch being processed (backup_batch retires the header)
 enum : int { ACT_COLLECT = 0, ACT_FINISH = 1 };
 
 __device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L, int wave, int pending, int nctx, int rootTeam, bool rootAdv, const NetOut* out, int rowBase, const PreSorted* pre) {
@@ -1890,7 +1897,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
-    __shared__ ExpLds s_exp2[2];                                    // expansion scratch of waves 2 and 3 (wave 1 uses L.exp)
+    __shared__ ExpLds s_exp2[3];                                    // expansion scratch of waves 2, 3 and 0 (wave 1 uses L.exp)
+    __shared__ int s_nextLeaf;                                      // process step: next context to expand (the four waves draw from it)
     __shared__ __attribute__((aligned(16))) Game s_game;
     constexpr int TABN = 512;
     __shared__ float s_cpuct[TABN];
@@ -1934,7 +1942,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     const int rootTeam = s_game.team;
     const bool rootAdv = s_game.adv != 0;
     const int rowBase = g * BATCH;
-    ExpLds& myExp = wave <= 1 ? L.exp : s_exp2[wave - 2];
+    ExpLds& myExp = wave == 1 ? L.exp : s_exp2[wave == 0 ? 2 : wave - 2];
     const PreSorted pre{pl.sortedMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES, pl.sortedPriors + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES};
     u64 tC = 0, tW = 0, tP = 0, nIt = 0;                            // thread 0: ticks spent collecting / waiting for the evaluator / processing
     unsigned xcc;                                                   // which XCD this workgroup runs on (diagnostics of a give-up)
@@ -2001,6 +2009,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             // hand-off state of one collect phase
             L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.createSeq = 0; L.svcStop = 0;
             L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
+            s_nextLeaf = 0;
             for (int i = 0; i < BATCH; ++i) L.postReady[i] = 0;
             // the root's own expansion (first batch of a search from a fresh root) mixes Dirichlet noise into the priors
             const bool rootRow = first && s_game.alpha > 0.0f && s_game.eps > 0.0f && !(s.nodes[s_game.root].flags & F_EXPANDED);
@@ -2026,15 +2035,52 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         }
         const int buf = s_ctl.buf;
         const bool first = s_ctl.first != 0;
-        u64 t0 = 0;
+        u64 t0 = 0, twIter = 0;                                     // thread 0: start of the collect phase; this iteration's wait for the evaluator (inside it)
         if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); mark(1u); }
         // ---- collect phase (collect_batch, searchthread.cc:255-442) into plane buffer `buf`
         PROF_T(tcp);
         if (wave == 0) {
             s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0;
-            collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
+            int tail[2];
+            collect_batch(s, s_rt, L, buf, rootTeam, rootAdv, tail);
             if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             HB(19);
+            if (!first) {
+                // ---- while the classifier wave finishes this batch's last leaf (its creation step is over; what is left writes that
+                // leaf's own node and context only, and no path of the batch before runs through it: it was reserved after that batch was
+                // collected) and the other helpers their rows: the ordered backups of the batch whose evaluation was requested one
+                // collect ago (process_batch, searchthread.cc:444-639).  The generator must be idle first: a sequential backup
+                // rewrites whole nodes, `more` included.
+                gen_wait(s);
+                const int pending = s_game.pending;
+                u64 tw0 = 0;
+                if (threadIdx.x == 0) {
+                    tw0 = __builtin_amdgcn_s_memrealtime();
+                    bool ok = true;
+                    mark(3u);
+                    if (s_game.validCount[pending] > 0) {
+                        ok = hmq::wait_count(io.q, &io.done[g * 2 + pending], s_expect[pending]);
+                        if (ok) hmq::acquire_agent();
+                        else if (atomicCAS(&io.q->dbg[0], 0u, (unsigned)g + 1u) == 0u) {
+                            io.q->dbg[1] = (unsigned)pending; io.q->dbg[2] = s_expect[pending];
+                            io.q->dbg[3] = __hip_atomic_load(hmq::G32(&io.done[g * 2 + pending]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            io.q->dbg[4] = (unsigned)nIt; io.q->dbg[5] = (unsigned)(((u64)__builtin_amdgcn_s_memrealtime() - tw0) / 100000ULL);
+                        }
+                    }
+                    s_ctl.ok = ok ? 1 : 0;
+                    if (ok) mark(4u); else io.progress[g] = 5u | (xcc << 4) | ((unsigned)nIt << 8);
+                    twIter = __builtin_amdgcn_s_memrealtime() - tw0;
+                    tW += twIter;
+                }
+                if (lane == 0) s_ctl.nctx = s_game.ctxCount[pending];      // the expansions' loop bound: backup_batch retires the batch header
+                wave_fence();
+                if (s_ctl.ok) {
+                    PROF_T(tpb);
+                    backup_batch(s, pending, &io.out[pending], rowBase);
+                    PROF_ADD(37, tpb);
+                }
+            }
+            collect_finish(s, L, buf, tail[0], tail[1] != 0);
         } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave, &s_pub);
         PROF_ADD(33, tcp);
         PROF_T(tcd);
@@ -2047,7 +2093,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         PROF_T(tpu);
         if (threadIdx.x == 0) {                                     // (the batch's rows went to the evaluator one by one: post_arrive)
             const u64 t1 = __builtin_amdgcn_s_memrealtime();
-            tC += t1 - t0; nIt++;
+            tC += t1 - t0 - twIter; nIt++;                          // (the backups of the batch before run inside this window too)
             mark(2u);
         }
         PROF_ADD(34, tpu);
@@ -2061,10 +2107,33 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
             __syncthreads();
             continue;
         }
-        // ---- process of the batch whose evaluation was requested one collect ago (process_batch, searchthread.cc:444-639)
-        if (!process_pending(false)) {
+        // ---- the rest of that batch's process step: its expansions (the backups ran on wave 0 beside the end of the collect phase;
+        // the barrier above also carries wave 0's acquire of the evaluator's results to the other waves)
+        if (!s_ctl.ok) {
             if (threadIdx.x == 0) { s_game.overflow |= 128; s_game.pending = -1; s_game.status = ST_ERROR; }
             break;
+        }
+        {
+            PROF_T(tpp);
+            u64 tp0 = 0;
+            if (threadIdx.x == 0) tp0 = __builtin_amdgcn_s_memrealtime();
+            const int pending = s_game.pending;
+            const int nctx = s_ctl.nctx;
+            {   // every wave (wave 0 has done its backups) draws the next leaf to expand
+                PROF_T(tpe);
+                for (;;) {
+                    int i = 0;
+                    if (lane == 0) i = atomicAdd(&s_nextLeaf, 1);
+                    i = ulane(i, 0);
+                    if (i >= nctx) break;
+                    expand_context(s, s_rt, myExp, pending, i, rootTeam, rootAdv, &io.out[pending], rowBase, &pre);
+                }
+                PROF_ADD_T(43, tpe, 64);
+            }
+            __threadfence_block();
+            __syncthreads();
+            PROF_ADD(36, tpp);
+            if (threadIdx.x == 0) tP += __builtin_amdgcn_s_memrealtime() - tp0;
         }
         PROF_T(ttl);
         if (wave == 0) {                                            // run_iteration tail
