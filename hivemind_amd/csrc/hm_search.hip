@@ -204,6 +204,18 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Orderings cheaper than wave_fence (whose workgroup-scope release drains every outstanding global store: ~1-2 k cycles):
+// wave_sync — the lanes of THIS wave see each other's earlier stores (wavefront scope: program order, no wait);
+// lds_release — this wave's LDS writes are done before the LDS flag that follows (another wave then reads LDS only).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_release() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 using hmp::hm_expf; using hmp::h2f; using hmp::finite_f; using hmp::clampf; using hmp::board_priors_sorted;   // hm_policy.hpp (shared with the persistent evaluator)
 
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ULL; }
@@ -246,6 +258,7 @@ struct G {               // per-wave view of one game's pools
     // `create` set) while the traversal is already selecting again.  `jPending`: that outcome is still unknown; resolve_create()
     // waits for it at every step the traversal could not take back.
     bool jPending, jTakenBack;
+    bool ldsTree;                    // the node pool is the LDS mirror: what the traversal reads of a leaf the classifier wave has finished is LDS only
     const int* createSeq;            // requests whose creation step is done
     const int* createFast;           // 1: the child stayed what the traversal assumed (a fresh leaf), 0: the traversal takes the descent back
     u32* dirty;                      // k_collect with the LDS node mirror: one bit per node the launch may have modified (nullptr otherwise)
@@ -744,7 +757,7 @@ __device__ inline void path_rebuild_history(const G& s, const TrajEnt* traj, int
         if (mvA) s.hist[0][s.g->hlen[0] + offA + __popcll(mA & below)] = kA;
         if (mvB) s.hist[1][s.g->hlen[1] + offB + __popcll(mB & below)] = kB;
     }
-    wave_fence();
+    wave_sync();                                                 // the keys are read back by this wave only (draw / repetition tests)
 }
 
 // searchthread.cc:741-806.  Returns: 0 = not expanded, 1 = expanded, 2 = pending (selection must abort).
@@ -1029,7 +1042,7 @@ __device__ inline G make_view(const Pools& pl, const Params& prm, int g) {
     s.ldsCpuct = nullptr; s.ldsPwRoot = nullptr; s.ldsPwNode = nullptr; s.tabN = 0;
     s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.ackSeq = nullptr; s.typeSeq = nullptr;
     s.genInflight = -1; s.genReqSeq = 0; s.genAckSeq = nullptr; s.gq = nullptr; s.nv = 0; s.es = 0; s.dirty = nullptr;
-    s.jPending = false; s.jTakenBack = false; s.createSeq = nullptr; s.createFast = nullptr;
+    s.jPending = false; s.jTakenBack = false; s.createSeq = nullptr; s.createFast = nullptr; s.ldsTree = false;
     return s;
 }
 
@@ -1282,8 +1295,15 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
             cr = canonicalize_child(s, rt, p, trajReq, rq.parent, rq.idx, next, childReserved, rootAdv, rootTeam, &pend);
         const bool fast = cr == 0 && next == leaf && childReserved == reserved;
         if (lane == 0) { L.createRes.fast = fast ? 1 : 0; L.createRes.cr = cr; L.createRes.next = next; L.createRes.reserved = childReserved ? 1 : 0; }
-        wave_fence();
-        if (lane == 0) __hip_atomic_store(&L.createSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // what the traversal reads once it knows the outcome: the result word and — only when the descent goes back to it — the
+        // edge and the nodes canonicalize_child changed (global memory unless the tree is the LDS mirror)
+        if (fast && s.ldsTree) {
+            lds_release();
+            if (lane == 0) __hip_atomic_store(&L.createSeq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            wave_fence();
+            if (lane == 0) __hip_atomic_store(&L.createSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         PROF_ADD_T(47, tcr, 64);
         if (!fast) {                                           // nothing is classified: the request ends here
             if (lane == 0) L.reqResult = 3;
@@ -1328,8 +1348,8 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
             L.postBuf = buf;
             L.postCount = np_ + 1;
         }
-        wave_fence();
-        if (lane == 0) __hip_atomic_store(&L.posted, np_ + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_release();                                         // the image, its row and the counters are LDS
+        if (lane == 0) __hip_atomic_store(&L.posted, np_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     int endInPly = 0, result = 0, newValid = valid;
     HB(23);
@@ -1346,8 +1366,13 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
     }
     // the leaf's Node is final: release the traversal's tree guards before the record keeping below
     if (lane == 0) L.reqResult = result;
-    wave_fence();
-    if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (s.ldsTree) {                                           // the leaf's node is LDS: nothing of this request that another wave reads before the batch ends is in global memory
+        lds_release();
+        if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        wave_fence();
+        if (lane == 0) __hip_atomic_store(&L.typeSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     HB(24);
     if constexpr (WT) { if (myPost >= 0) post_arrive(L, pc, myPost, result == 0 ? 4 : 8); }
     HB(25);
@@ -1363,7 +1388,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
         for (int i = lane; i < len; i += 64) dst[i] = trajReq[i];
     }
     if (lane == 0) L.svcValid = newValid;
-    wave_fence();
+    lds_release();                                             // (the context record and the path copy are read after the collect phase's closing barrier)
     PROF_ADD_T(23, tsv, 64);
 }
 
@@ -1670,7 +1695,7 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
             HB(21);
             serve_leaf<WT>(s, s_rt, L, rootTeam, rootAdv, seen, pc);
             HB(26);
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.ackSeq, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // behind serve_leaf's lds_release / fences
         }
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(&L.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         HB(29);
@@ -1794,7 +1819,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
         const uint4* src = reinterpret_cast<const uint4*>(gNodes);
         uint4* dst = reinterpret_cast<uint4*>(s_nodes);
         for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
-        s.nodes = reinterpret_cast<Node*>(s_nodes);
+        s.nodes = reinterpret_cast<Node*>(s_nodes); s.ldsTree = true;
         s.dirty = s_dirty;
         __syncthreads();
     }
@@ -1933,7 +1958,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         const uint4* src = reinterpret_cast<const uint4*>(gNodes);
         uint4* dst = reinterpret_cast<uint4*>(s_nodes);
         for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
-        s.nodes = reinterpret_cast<Node*>(s_nodes);
+        s.nodes = reinterpret_cast<Node*>(s_nodes); s.ldsTree = true;
         __syncthreads();
     }
     s.g = &s_game;
