@@ -480,8 +480,7 @@ __device__ inline bool scan_edges(G& s, const Node& n, EdgeScan& o) {   // false
     const bool dynFpu = s.prm->enableDynamicFpu && o.visits > 0;
     for (int base = 0; base < limit; base += 64) {
         const int i = base + lane;
-        float pr = 0.0f;
-        bool counted = false, nonLosing = false, unvisited = false;
+        bool nonLosing = false, unvisited = false;
         Edge ed;
         ed.child = -2;
         if (i < limit) ed = e[i];
@@ -492,15 +491,27 @@ __device__ inline bool scan_edges(G& s, const Node& n, EdgeScan& o) {   // false
         if (i < limit) {
             const int ct = s.nodes[ed.child].type;
             if (base == 0) { o.ed = ed; o.ct = ct; }
-            pr = ed.prior;
-            const bool touched = ed.visits + ed.vloss > 0;
-            counted = dynFpu && touched;
-            unvisited = !touched;
+            unvisited = ed.visits + ed.vloss <= 0;
             nonLosing = ct != T_WIN;
         }
         o.anyNonLosing |= wave_any(nonLosing);
         o.anyUnvisited |= wave_any(unvisited);
-        for (u64 m = __ballot(counted); m; m &= m - 1) o.visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
+    }
+    // The prior mass of the visited edges feeds only the first-play value of UNVISITED edges (node.cc:33-41): when every edge has been
+    // touched the selection never reads it, and the serial sum — ascending index order, as the reference adds — is skipped.
+    if (dynFpu && o.anyUnvisited) {
+        for (int base = 0; base < limit; base += 64) {
+            const int i = base + lane;
+            float pr = 0.0f;
+            bool counted = false;
+            if (i < limit) {
+                Edge ed = o.ed;
+                if (base != 0) ed = e[i];
+                pr = ed.prior;
+                counted = ed.visits + ed.vloss > 0;
+            }
+            for (u64 m = __ballot(counted); m; m &= m - 1) o.visitedPolicySum += ulanef(pr, __builtin_ctzll(m));   // ascending index order
+        }
     }
     return true;
 }
