@@ -1083,6 +1083,7 @@ int hm_net_can_serve(const hm_net* net) {
     const int ldx = net->nd.C + 8, polOff = (65 * std::max(ldx, 88) + 7) & ~7, need = 160 * 64 + hmn::PRIOR_SCRATCH_HALFS;
     return (polOff + need <= net->uHalfs || need <= 65 * ldx) ? 1 : 0;
 }
+int hm_net_serve_is_slow(const hm_net* net) { return net && net->nd.C >= 384 ? 1 : 0; }
 int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t st) {
     using namespace hmn;
     if (!hm_net_can_serve(net) || grid <= 0) return hm_fail(HM_ERR_INVALID, "hm_net_serve: this network has no persistent evaluator kernel");

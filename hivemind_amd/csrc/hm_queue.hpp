@@ -191,3 +191,5 @@ struct hm_net;
 int hm_net_can_serve(const hm_net* net);
 // hm_net.hip: launches `grid` persistent evaluator workgroups on `stream`; they leave when the queue hands them IT_POISON
 int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t stream);
+// hm_net.hip: 1 when one position takes this network's evaluator much longer than a game needs to collect a batch (the 384-channel trunk)
+int hm_net_serve_is_slow(const hm_net* net);

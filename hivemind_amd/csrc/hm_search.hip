@@ -2206,6 +2206,213 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     PROF_FLUSH();
 }
 
+// k_search for a SLOW evaluator (the deployed 384-channel network: 0.70 ms per position against 0.11 ms of tree work per batch):
+// one workgroup serves `perWg` games in turn instead of one, so that 64 games hold 16 CUs instead of 64 and the evaluator gets the
+// rest.  A game's turn is either a collect phase (then it waits for the evaluation of the batch before — the workgroup moves on to its
+// next game instead of spinning) or, once that evaluation is there, the process step (backups beside expansions) of that batch.  The
+// tree is walked in place (no LDS mirror: the games of a workgroup would have to swap it); per game the order of tree operations is the
+// one of k_search, hence every result.  Game record, rows published per buffer and the phase live in LDS per served game.
+constexpr int MG_MAX = 8;
+enum : int { MG_READY = 0, MG_WAIT_PROC = 1, MG_WAIT_FIN = 2, MG_DONE = 3 };
+struct MgSlot { int game, phase, pending; unsigned expect[2]; u64 since; };   // pending: the buffer whose evaluation the game waits for
+__global__ __launch_bounds__(COLLECT_THREADS) void k_search_mg(Pools pl, Params prm, SearchIo io, int nGames, int perWg) {
+    __shared__ RulesTab s_rt;
+    __shared__ WaveLds L;
+    __shared__ ExpLds s_exp2[2];                                    // expansion scratch of waves 2 and 3 (wave 1 uses L.exp)
+    __shared__ __attribute__((aligned(16))) Game s_game;
+    constexpr int TABN = 512;
+    __shared__ float s_cpuct[TABN];
+    __shared__ uint16_t s_pwRoot[TABN], s_pwNode[TABN];
+    __shared__ SearchCtl s_ctl;
+    __shared__ PubCtx s_pub;
+    __shared__ MgSlot s_slot[MG_MAX];
+    __shared__ int s_alive, s_moved, s_abort;
+    const int w = blockIdx.x, W = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    stage_table_wide(&s_rt, pl.rules);
+    {
+        const int g0 = w < nGames ? w : 0;
+        const bool alt = pl.games[g0].pwSel != 0;                   // (one profile per launch: the caller checks)
+        const int* pwr = alt ? pl.pwRootAlt : pl.pwRoot;
+        const int* pwn = alt ? pl.pwNodeAlt : pl.pwNode;
+        for (int i = threadIdx.x; i < TABN; i += COLLECT_THREADS) { s_cpuct[i] = pl.cpuctTab[i]; s_pwRoot[i] = (uint16_t)min(pwr[i], 65535); s_pwNode[i] = (uint16_t)min(pwn[i], 65535); }
+    }
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < MG_MAX; ++j) {
+            const int g = w + j * W;
+            s_slot[j].game = g; s_slot[j].expect[0] = s_slot[j].expect[1] = 0; s_slot[j].since = 0;
+            s_slot[j].phase = (j < perWg && g < nGames && pl.games[g].status == ST_SEARCHING) ? MG_READY : MG_DONE;
+        }
+        s_ctl.ok = 1; s_abort = 0; L.listWords = 0;
+        __hip_atomic_fetch_add(hmq::G32(&io.q->treesIn), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    u64 tC = 0, tW = 0, tP = 0, nIt = 0;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    ExpLds& myExp = wave <= 1 ? L.exp : s_exp2[wave - 2];
+    for (;;) {
+        if (threadIdx.x == 0) { s_alive = 0; s_moved = 0; }
+        __syncthreads();
+        for (int j = 0; j < perWg; ++j) {
+            const int phase = s_slot[j].phase;                      // uniform (LDS, written between barriers)
+            if (phase == MG_DONE) continue;
+            const int g = s_slot[j].game;
+            // ---- a waiting game: is the evaluation of its pending batch there?  (one relaxed load; the workgroup does not spin on it)
+            if (phase != MG_READY) {
+                if (threadIdx.x == 0) {
+                    s_alive++;
+                    const int pending = s_slot[j].pending;
+                    const unsigned have = __hip_atomic_load(hmq::G32(&io.done[g * 2 + pending]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int ready = have >= s_slot[j].expect[pending] ? 1 : 0;
+                    if (!ready) {
+                        const u64 now = __builtin_amdgcn_s_memrealtime();
+                        if (__hip_atomic_load(hmq::G32(&io.q->error), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; }
+                        else if (now - s_slot[j].since > hmq::SPIN_LIMIT_TICKS) { __hip_atomic_store(hmq::G32(&io.q->error), 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+                    } else {
+                        tW += (u64)__builtin_amdgcn_s_memrealtime() - s_slot[j].since;
+                        hmq::acquire_agent();
+                    }
+                    s_ctl.first = ready;                            // (reused as the "ready" broadcast)
+                }
+                __syncthreads();
+                const int ready = s_ctl.first;
+                const int stop = s_abort;
+                __syncthreads();                                    // (thread 0 reuses the broadcast words for the next game)
+                if (stop) break;
+                if (!ready) continue;
+            } else if (threadIdx.x == 0) s_alive++;
+            // ---- the game's turn: its record into LDS
+            __syncthreads();
+            G s = make_view(pl, prm, g);
+            Game* const gGame = s.g;
+            for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
+            __syncthreads();
+            s.g = &s_game;
+            s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
+            if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
+            const int rootTeam = s_game.team;
+            const bool rootAdv = s_game.adv != 0;
+            const int rowBase = g * BATCH;
+            const PreSorted pre{pl.sortedMoves + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES, pl.sortedPriors + (size_t)g * 2 * BATCH * 2 * HM_MAX_MOVES};
+            auto mark = [&](unsigned ph) {
+                __hip_atomic_store(hmq::G32(&io.progress[g]), ph | (xcc << 4) | ((unsigned)nIt << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hmq::G32(&io.progress[nGames + g]), (unsigned)((u64)__builtin_amdgcn_s_memrealtime() / 1000ULL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            // process step of the pending batch (its evaluation is there, or it is discarded): backups on wave 0 beside the expansions
+            auto process_now = [&](bool abortIt) {
+                u64 t0 = 0;
+                if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); mark(4u); }
+                const int pending = s_game.pending;
+                const int nctx = s_game.ctxCount[pending];
+                __syncthreads();                                    // every wave holds the batch header before wave 0 retires it
+                if (wave == 0) {
+                    if (abortIt) abort_batch(s, pending);
+                    else backup_batch(s, pending, &io.out[pending], rowBase);
+                } else if (!abortIt) expand_share(s, s_rt, myExp, wave, pending, nctx, rootTeam, rootAdv, &io.out[pending], rowBase, &pre);
+                __threadfence_block();
+                __syncthreads();
+                if (threadIdx.x == 0) tP += __builtin_amdgcn_s_memrealtime() - t0;
+            };
+            bool finished = false;
+            if (phase == MG_WAIT_FIN) {                             // finish_pending (agent.cc:343-352): the last batch, then the search ends
+                process_now(false);
+                finished = true;
+            } else {
+                if (phase == MG_WAIT_PROC) {                        // process_batch of the batch collected before the last one, then run_iteration's tail
+                    process_now(false);
+                    if (wave == 0) {
+                        const int look = 1 - s_game.pending;
+                        if (lane == 0) s_game.pending = -1;
+                        wave_fence();
+                        if (s_game.validCount[look] == 0) process_batch(s, s_rt, L.exp, look, rootTeam, rootAdv, nullptr, 0);
+                        else if (lane == 0) s_game.pending = look;
+                    }
+                    __syncthreads();
+                }
+                // ---- control (worker loop, agent.cc:331-341) and, unless the search ends, the next collect phase
+                if (threadIdx.x == 0) {
+                    const bool fin = s_game.nodesSearched >= s_game.targetNodes || s.nodes[s_game.root].type != T_UNSOLVED || s_game.overflow;
+                    const bool first = s_game.pending < 0;
+                    s_ctl.action = fin ? ACT_FINISH : ACT_COLLECT;
+                    s_ctl.first = first ? 1 : 0;
+                    s_ctl.buf = first ? 0 : 1 - s_game.pending;
+                    L.posted = 0; L.done = 0; L.servedCnt = 0; L.servedCntB = 0; L.postCount = 0; L.reqSeq = 0; L.typeSeq = 0; L.ackSeq = 0; L.createSeq = 0; L.svcStop = 0;
+                    L.svcValid = 0; L.reqResult = 0; L.gq.reqSeq = 0; L.gq.ackSeq = 0;
+                    for (int i = 0; i < BATCH; ++i) L.postReady[i] = 0;
+                    const bool rootRow = first && s_game.alpha > 0.0f && s_game.eps > 0.0f && !(s.nodes[s_game.root].flags & F_EXPANDED);
+                    const int bufNow = first ? 0 : 1 - s_game.pending;
+                    s_pub.q = io.q; s_pub.expect = &s_slot[j].expect[bufNow];
+                    s_pub.itemBase = hmq::item_pack(g, bufNow, 0, io.netSel ? io.netSel[g] : 0) | (rootRow ? hmq::IT_ROOT : 0u);
+                }
+                __syncthreads();
+                if (s_ctl.action == ACT_FINISH) {
+                    if (s_game.pending >= 0) {
+                        const bool solvedOrOverflow = s.nodes[s_game.root].type != T_UNSOLVED || s_game.overflow;
+                        if (solvedOrOverflow || s_game.validCount[s_game.pending] == 0) { process_now(solvedOrOverflow); finished = true; }   // discard / nothing to wait for
+                        else if (threadIdx.x == 0) { s_slot[j].phase = MG_WAIT_FIN; s_slot[j].pending = s_game.pending; s_slot[j].since = __builtin_amdgcn_s_memrealtime(); mark(3u); }
+                    } else finished = true;
+                } else {
+                    const int buf = s_ctl.buf;
+                    const bool first = s_ctl.first != 0;
+                    u64 t0 = 0;
+                    if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); mark(1u); }
+                    if (wave == 0) {
+                        s.inflight = -1; s.reqSeq = 0; s.svcBusy = false; s.genInflight = -1; s.genReqSeq = 0; s.nv = 0; s.es = 0;
+                        collect_batch(s, s_rt, L, buf, rootTeam, rootAdv);
+                        if (lane == 0) __hip_atomic_store(&L.svcStop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0) { s_game.nodesVisited += s.nv; s_game.edgesScanned += s.es; }
+                    } else collect_helper_role<true>(s, s_rt, L, pl, s_game, g, io.planes[buf], wave, &s_pub);
+                    hmq::drain_stores();
+                    __syncthreads();
+                    if (threadIdx.x == 0) { tC += __builtin_amdgcn_s_memrealtime() - t0; nIt++; mark(2u); s_game.listWords += L.listWords; L.listWords = 0; }
+                    if (first) {
+                        if (wave == 0) {
+                            if (s_game.ctxCount[0] == 0) { if (lane == 0) s_game.overflow |= 16; }
+                            else if (s_game.validCount[0] == 0) process_batch(s, s_rt, L.exp, 0, rootTeam, rootAdv, nullptr, 0);
+                            else if (lane == 0) s_game.pending = 0;
+                            if (lane == 0) s_slot[j].phase = MG_READY;     // its lookahead batch follows at its next turn (the turn may have begun as a waiting one)
+                        }
+                        __syncthreads();
+                    } else if (threadIdx.x == 0) {
+                        // (a pending batch without network rows has nothing to wait for: expect == done, ready at its next turn)
+                        s_slot[j].phase = MG_WAIT_PROC; s_slot[j].pending = s_game.pending; s_slot[j].since = __builtin_amdgcn_s_memrealtime(); mark(3u);
+                    }
+                }
+            }
+            __syncthreads();
+            if (finished && threadIdx.x == 0) {
+                s_game.pending = -1;
+                s_game.status = s_game.overflow ? ST_ERROR : ST_DONE;
+                s_slot[j].phase = MG_DONE;
+                io.progress[2 * nGames + g] = (unsigned)((u64)__builtin_amdgcn_s_memrealtime() / 1000ULL);   // when it left
+                io.progress[3 * nGames + g] = s_slot[j].expect[0] + s_slot[j].expect[1] + 1u;               // rows it published (+ 1)
+            }
+            if (threadIdx.x == 0) s_moved = 1;
+            __syncthreads();
+            for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(gGame)[i] = reinterpret_cast<const u32*>(&s_game)[i];
+            __syncthreads();
+        }
+        __syncthreads();
+        if (s_abort) {                                              // the evaluator is gone: every game still searching ends in error
+            if (threadIdx.x == 0)
+                for (int j = 0; j < perWg; ++j)
+                    if (s_slot[j].phase != MG_DONE) { Game& gm = pl.games[s_slot[j].game]; gm.overflow |= 128; gm.pending = -1; gm.status = ST_ERROR; }
+            break;
+        }
+        if (s_alive == 0) break;
+        if (!s_moved) __builtin_amdgcn_s_sleep(16);                 // every game of this workgroup is waiting for the evaluator
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LegClock* ck = pl.clk;
+        atomicAdd(&ck->sumC, tC); atomicAdd(&ck->sumW, tW); atomicAdd(&ck->sumP, tP);
+        atomicAdd(&ck->cntC, nIt); atomicAdd(&ck->cntP, nIt);
+        __hip_atomic_fetch_add(hmq::G32(&io.q->treesOut), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hmq::producer_exit(io.q);
+    }
+}
+
 // Holds the evaluator's stream until every search workgroup has started (k_search is launched first, on the other stream): the
 // games then own their CUs before the evaluator kernel takes ALL the others.  Evaluator workgroups that find no CU simply wait in the
 // dispatcher until games end (each gets its poison item then); the reverse order could leave a game workgroup waiting for a CU that
@@ -3264,8 +3471,18 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     if (!io->planes[0] || !io->planes[1] || !io->value || !io->pi_a || !io->pi_b || !io->wdl || !io->moves_left
         || !io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2) return hm_fail(HM_ERR_INVALID, "hm_sp_search needs both plane buffers and both sets of heads");
     if (!hm_net_can_serve(net)) return hm_fail(HM_ERR_INVALID, "this network has no persistent evaluator kernel");
-    const int consumers = hm_sp_search_consumers(sp);
+    int consumers = hm_sp_search_consumers(sp);
     if (consumers <= 0) return hm_fail(HM_ERR_INVALID, "too many game slots for a persistent search on this device (use the lockstep calls)");
+    // A slow evaluator (the 384-channel deployed network: 0.70 ms per position against ~0.11 ms of tree work per batch) is the limit of
+    // the whole search: one search workgroup then serves several games in turn (k_search_mg) and the CUs it frees go to the evaluator.
+    // HM_SEARCH_GAMES_PER_WG=k overrides (1 = one workgroup per game).
+    int perWg = hm_net_serve_is_slow(net) ? 3 : 1;             // measured at configs[3]: 518 / 546 / 550 / 529 positions/s with 1 / 2 / 3 / 4 games per workgroup
+    if (const char* e = std::getenv("HM_SEARCH_GAMES_PER_WG")) perWg = std::max(1, std::min(MG_MAX, std::atoi(e)));
+    const int searchWgs = perWg > 1 ? (sp->nGames + perWg - 1) / perWg : sp->nGames;
+    if (perWg > 1) {
+        const int act = std::min(sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames, sp->nGames);
+        consumers = std::max(8, std::min(sp->numCUs - searchWgs, 2 * BATCH * act + 8));
+    }
     // The two kernels must RUN TOGETHER, so they need two hardware queues: ordinary HIP streams are multiplexed onto a small pool of
     // queues and two of them may share one (the second kernel would then wait for the first to end — which waits for the second).
     // Streams created with a CU mask own their queue; the mask enables every CU.
@@ -3303,7 +3520,7 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     unsigned* done = reinterpret_cast<unsigned*>(sp->d_queue + sizeof(hmq::SrvQueue));
     // every polled word starts from zero; then the two head counts (producers .. consumers are adjacent words)
     HIPCHK(hipMemsetAsync(sp->d_queue, 0, sp->queueBytes, sT));
-    sp->h_qinit[0] = (unsigned)sp->nGames; sp->h_qinit[1] = 0u; sp->h_qinit[2] = (unsigned)consumers; sp->h_qinit[3] = (unsigned)sp->nGames;
+    sp->h_qinit[0] = (unsigned)searchWgs; sp->h_qinit[1] = 0u; sp->h_qinit[2] = (unsigned)consumers; sp->h_qinit[3] = (unsigned)sp->nGames;
 #ifdef HM_SEARCH_HB
     {
         unsigned* hbp = done + (size_t)sp->nGames * 5;
@@ -3331,11 +3548,12 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     for (int b = 0; b < 2; ++b) sio.out[b] = NetOut{a.value[b], a.piA[b], a.piB[b], a.wdl[b], a.ml[b]};
     sio.q = q; sio.done = done; sio.progress = done + (size_t)sp->nGames * 2; sio.netSel = nullptr; sio.ldsNodes = sp->searchLdsNodes;
     (void)hipEventRecord(sp->evT0, sT);            // HIP events on the stream the kernel is launched on: its launch duration
-    hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
+    if (perWg > 1) hipLaunchKernelGGL(k_search_mg, dim3(searchWgs), dim3(COLLECT_THREADS), 0, sT, sp->pl, sp->prm, sio, sp->nGames, perWg);
+    else hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
     const hipError_t le = hipGetLastError();
     (void)hipEventRecord(sp->evT1, sT);
     if (le != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("k_search launch failed: ") + hipGetErrorString(le));
-    hipLaunchKernelGGL(k_wait_trees, dim3(1), dim3(64), 0, sN, q, (unsigned)sp->nGames);
+    hipLaunchKernelGGL(k_wait_trees, dim3(1), dim3(64), 0, sN, q, (unsigned)searchWgs);
     int rcServe = hipGetLastError() == hipSuccess ? 0 : hm_fail(HM_ERR_NO_DEVICE, "k_wait_trees launch failed");
     if (!rcServe) rcServe = hm_net_serve(net, a, consumers, sN);
     if (rcServe) {
