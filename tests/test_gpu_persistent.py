@@ -144,3 +144,31 @@ def test_stalled_persistent_search_is_repeated_with_the_same_records(hm, monkeyp
     assert res_b.persistent_stalls + res_b.persistent_searches == res_a.persistent_searches
     assert cnt_b == cnt_a and rec_b == rec_a
     assert (res_b.samples, res_b.total_nodes) == (res_a.samples, res_a.total_nodes)
+
+
+@pytest.mark.parametrize("per_wg", [2, 4])
+def test_several_games_per_search_workgroup_equal_lockstep(hm, monkeypatch, per_wg):
+    """k_search_mg (the form hm_sp_search takes for a slow evaluator — the deployed 384-channel network —: one search workgroup serves
+    several games in turn, tree walked in place, the freed CUs go to the evaluator), forced here onto the small network: root statistics
+    of every game and whole self-play records equal the lockstep loop's."""
+    monkeypatch.setenv("HM_SEARCH_GAMES_PER_WG", str(per_wg))
+    net = _net()
+    G, nodes = 30, 200
+    roots = O.random_positions(4242, G * 7, 120)[::7][:G].copy()
+    seeds = (np.arange(G, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(99)
+    eng = hm.SearchEngine(G, 221)
+    eng.set_games(roots)
+    eng.begin_search(nodes, seeds, 0.3, 0.25)
+    eng.run(net)
+    want = eng.root_stats()
+    eng.set_games(roots)
+    eng.begin_search(nodes, seeds, 0.3, 0.25)
+    assert eng.search_persistent(net) > 0.0
+    _stats_equal(want, eng.root_stats(), G)
+    eng.close()
+    kw = dict(games=10, nodes=64, seed=21, concurrent_games=10, max_macro_plies=50)
+    res_p, rec_p, cnt_p = _selfplay(hm, net, **kw)
+    monkeypatch.setenv("HM_SELFPLAY_LOCKSTEP", "1")
+    res_l, rec_l, cnt_l = _selfplay(hm, net, **kw)
+    assert res_p.persistent_searches > 0 and res_l.persistent_searches == 0
+    assert cnt_p == cnt_l and rec_p == rec_l
