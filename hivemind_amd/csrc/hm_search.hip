@@ -1194,7 +1194,7 @@ __device__ inline int ctx_row(const G& s, int buf, int i) {   // inference row o
     const bool nn = lane < i && !s.ctx[buf * BATCH + lane].terminal;      // i <= BATCH: one context per lane
     return __popcll(__ballot(nn));
 }
-__device__ inline void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase, const PreSorted* pre = nullptr) {
+__device__ __forceinline__ void expand_context(G& s, const RulesTab& rt, ExpLds& L, int buf, int i, int rootTeam, bool rootAdv, const NetOut* out, int rowBase, const PreSorted* pre = nullptr) {
     const Ctx& ctx = s.ctx[buf * BATCH + i];
     if (ctx.terminal) return;
     if (s.nodes[ctx.leaf].type != T_UNSOLVED) return;
@@ -3424,6 +3424,8 @@ int hm_sp_search_not_concurrent(const hm_sp* sp) { return sp && sp->lastQueueErr
 // 1 when the last hm_sp_search was given up because the evaluator had nothing to do for 30 ms while games were still searching
 // (hm_queue.hpp: IDLE_LIMIT_TICKS): hm_sp_begin_again + another search (persistent or lockstep) repeats it with the same result.
 int hm_sp_search_stalled(const hm_sp* sp) { return sp && sp->lastQueueError == 5u ? 1 : 0; }
+// 1 when k_search keeps this engine's node pool in LDS for a whole search (it fits beside the kernel's static LDS), 0 when the tree is walked in place
+int hm_sp_search_lds_tree(const hm_sp* sp) { return sp && sp->searchLdsNodes ? 1 : 0; }
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,

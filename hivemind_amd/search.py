@@ -60,6 +60,7 @@ _SIGS = {
     "hm_sp_search_consumers": (_i, [_vp]),
     "hm_sp_search_not_concurrent": (_i, [_vp]),
     "hm_sp_search_stalled": (_i, [_vp]),
+    "hm_sp_search_lds_tree": (_i, [_vp]),
     "hm_sp_begin_again": (_i, [_vp]),
     "hm_sp_wait_time": (_i, [_vp, C.POINTER(C.c_double)]),
     "hm_sp_trace_select": (_i, [_i]),
@@ -189,6 +190,9 @@ class SearchEngine:
 
     def search_consumers(self) -> int:
         return int(lib.hm_sp_search_consumers(self.h))
+
+    def search_lds_tree(self) -> bool:
+        return bool(lib.hm_sp_search_lds_tree(self.h))
 
     def leg_times(self, reset=False):
         """Device-clock totals since the last reset: (ms[collect, forward, process], launches[3]).  Synchronise first."""

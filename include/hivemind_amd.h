@@ -243,6 +243,9 @@ int hm_sp_search_not_concurrent(const hm_sp* sp);
  * searching (observed on MI355X about once in 800 searches with the deployed network; see hm_queue.hpp).  hm_sp_begin_again puts
  * every slot back to the start of that search; running it again — persistent or lockstep — gives the same result. */
 int hm_sp_search_stalled(const hm_sp* sp);
+/* 1 when the persistent search keeps this engine's node pool in LDS for a whole search (the pool fits beside k_search's static LDS:
+ * node budgets up to about 1 500 nodes), 0 when it walks the tree in place. */
+int hm_sp_search_lds_tree(const hm_sp* sp);
 int hm_sp_begin_again(hm_sp* sp);
 /* Evaluator workgroups a persistent search of this engine runs (0: not available for this many game slots on this device). */
 int hm_sp_search_consumers(const hm_sp* sp);

@@ -172,3 +172,12 @@ def test_several_games_per_search_workgroup_equal_lockstep(hm, monkeypatch, per_
     res_l, rec_l, cnt_l = _selfplay(hm, net, **kw)
     assert res_p.persistent_searches > 0 and res_l.persistent_searches == 0
     assert cnt_p == cnt_l and rec_p == rec_l
+
+
+def test_node_pool_of_the_headline_budget_fits_lds(hm):
+    """BASELINE configs[2] / [3] (nodes 400: the self-play driver sizes the pool for 400 * 1.05 + 1 = 421 nodes): k_search must be able to keep the pool
+    in LDS beside its static LDS.  A regression guard: one more LDS array in the kernel — or a helper the compiler stops inlining, whose
+    LDS arguments then get allocated in every kernel that reaches it — silently sends the traversal back to global memory (-20 %)."""
+    eng = hm.SearchEngine(64, 421)
+    assert eng.search_lds_tree()
+    eng.close()
