@@ -28,6 +28,9 @@
 
 int hm_fail(int code, const std::string& msg);
 
+#ifndef HM_NPF_WIDE
+#define HM_NPF_WIDE 10            // weight-fragment requests a wave keeps in flight in the 384-channel variant (build parameter for measurements)
+#endif
 namespace hmn {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -639,7 +642,7 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
     // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
     // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
     // per chunk of copMax channels and carries the projection accumulators across the chunks in registers.
-    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8, NPF = CTILES > 4 ? 16 : 8;
+    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8, NPF = CTILES > 4 ? HM_NPF_WIDE : 8;
     h16* Xs = reinterpret_cast<h16*>(smem);                             // [65][ldx]
     h16* U = Xs + 65 * ldx;                                             // union region
     h16* Ss = U;                                                        // [65][ldx] (input staging uses pitch ldi)
