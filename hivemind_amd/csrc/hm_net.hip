@@ -28,6 +28,9 @@
 
 int hm_fail(int code, const std::string& msg);
 
+#ifndef HM_NPF_PROJ
+#define HM_NPF_PROJ 0      // the same for the 1x1 projection of the 384-channel variant (its accumulators are live across the chunks)
+#endif
 #ifndef HM_NPF_WIDE
 #define HM_NPF_WIDE 10            // weight-fragment requests a wave keeps in flight in the 384-channel variant (build parameter for measurements)
 #endif
@@ -642,7 +645,7 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
     // TPW tiles per wave (tile t = wave + 8i; its square half t & 1 is the wave's own).  copMax = the expanded channels kept
     // in LDS at a time: a block whose `cop` exceeds it (the 384-channel deployed net: cop up to 1152) runs its three phases
     // per chunk of copMax channels and carries the projection accumulators across the chunks in registers.
-    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8, NPF = CTILES > 4 ? HM_NPF_WIDE : 8;
+    constexpr int C = CTILES * 32, ldx = C + 8, ctiles = CTILES, TPW = (2 * CTILES + 7) / 8, NPF = CTILES > 4 ? HM_NPF_WIDE : 8, NPFP = (CTILES > 4 && HM_NPF_PROJ > 0) ? HM_NPF_PROJ : NPF;
     h16* Xs = reinterpret_cast<h16*>(smem);                             // [65][ldx]
     h16* U = Xs + 65 * ldx;                                             // union region
     h16* Ss = U;                                                        // [65][ldx] (input staging uses pitch ldi)
@@ -809,7 +812,7 @@ __device__ __forceinline__ void narrow_position(const NetDesc& nd, const h16* __
                 for (int i = 0; i < TPW; ++i) {
                     const int ctile = (wave + 8 * i) >> 1;
                     if (ctile < ctiles)
-                        pacc[i] = gemm_tile<false, NPF>(pacc[i], Y2 + sqL * ld2 + kh, chunk >> 4, w2c, ctiles, ctile, lane);
+                        pacc[i] = gemm_tile<false, NPFP>(pacc[i], Y2 + sqL * ld2 + kh, chunk >> 4, w2c, ctiles, ctile, lane);
                 }
                 // (no barrier here: the next chunk's parameter stage and expand phase touch Pf / Pdw / Y1, which this phase does
                 // not read, and its depthwise phase — the next writer of Y2 — starts behind the barrier after its expand phase)
