@@ -29,6 +29,7 @@
 //     schedule come from host-built tables (std::log / std::pow, the reference's own expressions), Dirichlet gamma draws
 //     are made on the host with std::gamma_distribution<float> on std::mt19937_64 exactly as node.h:286-315.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <algorithm>
 #include <cmath>
@@ -2515,14 +2516,22 @@ __device__ inline int find_reusable_root(const G& s, int prevRoot, u64 hash, int
 }
 
 // Agent::run_search prologue (agent.cc:421-558): early outs, 1-ply root mate scan, root + TT setup.
-__global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* targetNodes, const u64* noiseSeeds, float alpha, float eps, const uint8_t* searchMask, u64* rootHashOut) {
+// rootSig (pinned host memory, or nullptr): [2 g] = root hash, [2 g + 1] = (legal moves + pass) per board, published with system
+// scope the moment they are known, so that the host can make the game's Dirichlet draws while this kernel goes on with the root
+// mate scan; the host presets [2 g + 1] to ~0 ("not yet") and every path through the kernel stores it exactly once.
+__device__ __forceinline__ void root_signal(u64* rootSig, int g, u64 hash, u64 counts) {
+    if (!rootSig || (threadIdx.x & 63) != 0) return;
+    __hip_atomic_store(&rootSig[2 * g], hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&rootSig[2 * g + 1], counts, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* targetNodes, const u64* noiseSeeds, float alpha, float eps, const uint8_t* searchMask, u64* rootHashOut, u64* rootSig) {
     __shared__ RulesTab s_rt;
     __shared__ WaveLds L;
     stage_table(&s_rt, pl.rules);
     __syncthreads();
     const int g = blockIdx.x, lane = threadIdx.x & 63;
     G s = make_view(pl, prm, g);
-    if ((searchMask && !searchMask[g]) || !s.g->live) { s.g->status = ST_IDLE; s.g->root = -1; rootHashOut[2 * g] = 0; rootHashOut[2 * g + 1] = 0; return; }
+    if ((searchMask && !searchMask[g]) || !s.g->live) { s.g->status = ST_IDLE; s.g->root = -1; rootHashOut[2 * g] = 0; rootHashOut[2 * g + 1] = 0; root_signal(rootSig, g, 0, 0); return; }
     const RulesTab& rt = s_rt;
     for (int i = lane; i < prm.ttCap; i += 64) s.ttVals[i] = -1;
     wave_fence();
@@ -2548,9 +2557,9 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
     rootHashOut[2 * g] = rootHash;
     rootHashOut[2 * g + 1] = 0;              // (legal moves + pass) per board, for the host's Dirichlet draws
     const bool mateUs = is_checkmate(rt, p.jb.bd, team, adv, scratch);
-    if (is_checkmate(rt, p.jb.bd, team ^ 1, !adv, scratch) || mateUs || jb_is_draw(p.jb, 0)) { gm.status = ST_NOACTION; return; }
+    if (is_checkmate(rt, p.jb.bd, team ^ 1, !adv, scratch) || mateUs || jb_is_draw(p.jb, 0)) { gm.status = ST_NOACTION; root_signal(rootSig, g, rootHash, 0); return; }
     const int cA = aOn ? count_legal(rt.att, p.jb.bd[0]) : 0, cB = bOn ? count_legal(rt.att, p.jb.bd[1]) : 0;
-    if (cA + cB == 0 && !canWait) { gm.status = ST_NOACTION; return; }
+    if (cA + cB == 0 && !canWait) { gm.status = ST_NOACTION; root_signal(rootSig, g, rootHash, 0); return; }
     // ---- find_immediate_root_mate (agent.cc:136-238).  The reference walks the candidates
     // sequentially; here every candidate is pre-filtered lane-parallel with a necessary condition
     // for Board::is_checkmate (some on-turn board of the victim has no legal move), and only the
@@ -2565,6 +2574,7 @@ __global__ __launch_bounds__(64) void k_begin(Pools pl, Params prm, const int* t
         if (aOn) nA = gen_legal_wave(rt.att, p.jb.bd[0], la);
         if (bOn) nB = gen_legal_wave(rt.att, p.jb.bd[1], lb);
         rootHashOut[2 * g + 1] = (u64)(u32)(nA + 1) | ((u64)(u32)(nB + 1) << 32);
+        root_signal(rootSig, g, rootHash, (u64)(u32)(nA + 1) | ((u64)(u32)(nB + 1) << 32));
         __builtin_amdgcn_wave_barrier();
         const bool aChk = checkers_of(rt.att, p.jb.bd[0]) != 0, bChk = checkers_of(rt.att, p.jb.bd[1]) != 0;
         for (int i = lane; i < nA; i += 64) flA[i] = (gives_check(rt, p.jb.bd[0], la[i]) ? 1u : 0u) | (is_capture(p.jb.bd[0], la[i]) ? 2u : 0u);
@@ -3046,6 +3056,8 @@ struct hm_sp {
     // device outputs
     RootOut ro;
     u64* d_rootHash;
+    u64* h_rootSig = nullptr;              // pinned, device-visible: k_begin publishes root hash / action counts per game here (root_signal)
+    float* h_noise = nullptr;              // pinned staging of the Dirichlet draws
     int* d_active;
     int* d_target;
     u64* d_seed;
@@ -3342,6 +3354,8 @@ int hm_sp_destroy(hm_sp* sp) {
     if (!sp) return 0;
     if (sp->h_stage) (void)hipHostFree(sp->h_stage);
     if (sp->h_qinit) (void)hipHostFree(sp->h_qinit);
+    if (sp->h_rootSig) (void)hipHostFree(sp->h_rootSig);
+    if (sp->h_noise) (void)hipHostFree(sp->h_noise);
     if (sp->evFork) (void)hipEventDestroy(sp->evFork);
     if (sp->evJoin) (void)hipEventDestroy(sp->evJoin);
     if (sp->evT0) (void)hipEventDestroy(sp->evT0);
@@ -3365,22 +3379,6 @@ int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask) {
 
 // Dirichlet gamma draws exactly as node.h:286-315 (std::gamma_distribution<float> on std::mt19937_64
 // seeded rootNoiseSeed ^ positionHash ^ salt); the device mixes them into the root priors.
-static void fill_noise(hm_sp* sp, const uint64_t* seeds, float alpha, std::vector<float>& buf) {
-    buf.assign((size_t)sp->nGames * 2 * NOISE_CAP, 0.0f);
-    static const uint64_t salts[2] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL};
-    for (int g = 0; g < sp->nGames; ++g)
-        for (int b = 0; b < 2; ++b) {
-            // one draw per root action of this board (node.h:286-315); a single action takes no noise
-            int n = (int)((sp->h_rootHash[2 * g + 1] >> (32 * b)) & 0xffffffffu);
-            if (n <= 1) continue;
-            if (n > NOISE_CAP) n = NOISE_CAP;
-            std::mt19937_64 eng(seeds[g] ^ sp->h_rootHash[2 * g] ^ salts[b]);
-            std::gamma_distribution<float> gamma(alpha, 1.0f);
-            float* dst = buf.data() + ((size_t)g * 2 + b) * NOISE_CAP;
-            for (int i = 0; i < n; ++i) dst[i] = gamma(eng);
-        }
-}
-
 int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise_seeds, float alpha, float eps, const uint8_t* mask) {
     if (!sp || !target_nodes) return hm_fail(HM_ERR_INVALID, "null argument");
     const int G_ = sp->nGames;
@@ -3392,15 +3390,48 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
     if (mask) std::memcpy(hs + (sp->d_mask - sp->d_in), mask, (size_t)G_);
     const size_t upTo = (size_t)(sp->d_mask - sp->d_in) + (size_t)G_;
     HIPCHK(hipMemcpy(sp->d_in, hs, upTo, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_begin, dim3(G_), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, alpha, eps, mask ? sp->d_mask : nullptr, sp->d_rootHash);
+    const bool noisy = alpha > 0.0f && eps > 0.0f;
+    if (noisy && !sp->h_rootSig) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&sp->h_rootSig), 16 * (size_t)G_, hipHostMallocDefault) != hipSuccess
+            || hipHostMalloc(reinterpret_cast<void**>(&sp->h_noise), (size_t)G_ * 2 * NOISE_CAP * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed");
+        }
+        std::memset(sp->h_noise, 0, (size_t)G_ * 2 * NOISE_CAP * sizeof(float));
+    }
+    std::vector<uint64_t> seedCopy;
+    if (noisy) {
+        seedCopy.assign(seeds, seeds + G_);                        // (the staging block may be reused)
+        for (int g = 0; g < G_; ++g) { sp->h_rootSig[2 * g] = 0; sp->h_rootSig[2 * g + 1] = ~0ULL; }
+    }
+    hipLaunchKernelGGL(k_begin, dim3(G_), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, alpha, eps, mask ? sp->d_mask : nullptr, sp->d_rootHash, noisy ? sp->h_rootSig : nullptr);
     HIPCHK(hipGetLastError());
-    if (alpha > 0.0f && eps > 0.0f) {
-        std::vector<uint64_t> seedCopy(seeds, seeds + G_);       // the staging block is reused by the download below
-        HIPCHK(hipMemcpy(hs, sp->d_rootHash, 16 * (size_t)G_, hipMemcpyDeviceToHost));
-        std::memcpy(sp->h_rootHash.data(), hs, 16 * (size_t)G_);
-        std::vector<float> nz;
-        fill_noise(sp, seedCopy.data(), alpha, nz);
-        HIPCHK(hipMemcpy(sp->pl.noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (noisy) {
+        // The Dirichlet draws (node.h:286-315: std::gamma_distribution on std::mt19937_64 seeded from the root hash) are made here while
+        // k_begin is still scanning the roots for immediate mates: each game publishes its hash and action counts as soon as they are known.
+        volatile uint64_t* sig = sp->h_rootSig;
+        static const uint64_t salts[2] = {0x9e3779b97f4a7c15ULL, 0xbf58476d1ce4e5b9ULL};
+        unsigned spins = 0;
+        for (int g = 0; g < G_; ++g) {
+            while (sig[2 * g + 1] == ~0ULL) {
+                if ((++spins & 0x3fffu) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady) {   // the kernel has ended (or failed): whatever it wrote is there now
+                    if (sig[2 * g + 1] == ~0ULL) return hm_fail(HM_ERR_STATE, "k_begin left a root without its action counts");
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            const uint64_t hash = sig[2 * g], counts = sig[2 * g + 1];
+            sp->h_rootHash[2 * g] = hash; sp->h_rootHash[2 * g + 1] = counts;
+            for (int b = 0; b < 2; ++b) {
+                float* dst = sp->h_noise + ((size_t)g * 2 + b) * NOISE_CAP;
+                int n = (int)((counts >> (32 * b)) & 0xffffffffu);
+                if (n <= 1) continue;                             // a single action takes no noise (stale draws of an earlier search are never read)
+                if (n > NOISE_CAP) n = NOISE_CAP;
+                std::mt19937_64 eng(seedCopy[g] ^ hash ^ salts[b]);
+                std::gamma_distribution<float> gamma(alpha, 1.0f);
+                for (int i = 0; i < n; ++i) dst[i] = gamma(eng);
+            }
+        }
+        HIPCHK(hipMemcpyAsync(sp->pl.noise, sp->h_noise, (size_t)G_ * 2 * NOISE_CAP * sizeof(float), hipMemcpyHostToDevice, nullptr));   // behind k_begin on its stream
     }
     sp->alpha = alpha; sp->eps = eps;
     sp->lastBeginMasked = mask != nullptr;
@@ -3413,7 +3444,7 @@ int hm_sp_begin_search(hm_sp* sp, const int* target_nodes, const uint64_t* noise
 // Only valid with tree reuse off and before any other hm_sp_* call that uploads moves or masks.
 int hm_sp_begin_again(hm_sp* sp) {
     if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
-    hipLaunchKernelGGL(k_begin, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, sp->alpha, sp->eps, sp->lastBeginMasked ? sp->d_mask : nullptr, sp->d_rootHash);
+    hipLaunchKernelGGL(k_begin, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_target, sp->d_seed, sp->alpha, sp->eps, sp->lastBeginMasked ? sp->d_mask : nullptr, sp->d_rootHash, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
