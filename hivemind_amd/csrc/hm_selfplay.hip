@@ -127,6 +127,7 @@ struct hm_selfplay {
     hm_selfplay_result res{};
     hm_board* d_boards = nullptr;
     uint8_t* d_u8 = nullptr;
+    uint8_t* h_u8 = nullptr;                // pinned: the u8 planes of the searched positions, for the records
     std::vector<uint64_t> termCounts = std::vector<uint64_t>(5, 0);
     std::vector<hipEvent_t> evs, sync;                 // ring of per-iteration leg events
     hipStream_t sT = nullptr, sN = nullptr;      // tree / network streams (native evaluator mode)
@@ -551,6 +552,7 @@ int hm_selfplay_destroy(hm_selfplay* s) {
     if (s->sT) (void)hipStreamDestroy(s->sT);
     if (s->sN && s->sN != s->sT) (void)hipStreamDestroy(s->sN);
     if (s->hActive) (void)hipHostFree(s->hActive);
+    if (s->h_u8) (void)hipHostFree(s->h_u8);
     if (s->stepGraph) (void)hipGraphExecDestroy(s->stepGraph);
     if (s->gFork) (void)hipEventDestroy(s->gFork);
     if (s->gJoin) (void)hipEventDestroy(s->gJoin);
@@ -620,7 +622,9 @@ static int selfplay_run_impl(hm_selfplay* s) {
     const int E = hm_sp_max_edges(s->sp);
     std::vector<hm_board> boards(G);
     std::vector<int> flags(G), counts(G), term(G);
-    std::vector<uint8_t> mask(G), u8planes((size_t)G * HM_PLANE_VALUES);
+    std::vector<uint8_t> mask(G);
+    const size_t u8bytes = (size_t)G * HM_PLANE_VALUES;
+    if (!s->h_u8 && hipHostMalloc(reinterpret_cast<void**>(&s->h_u8), u8bytes, hipHostMallocDefault) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipHostMalloc failed");
     std::vector<hm_move> mA((size_t)G * E), mB((size_t)G * E), actA(G), actB(G);
     std::vector<int> visits((size_t)G * E), target(G), info((size_t)G * HM_SP_INFO_INTS);
     std::vector<float> rootQ(G);
@@ -736,7 +740,8 @@ static int selfplay_run_impl(hm_selfplay* s) {
         for (int g = 0; g < G; ++g) { mask[g] = s->slots[g].active && !movedRaw[g]; anySearch |= mask[g] != 0; }
         if (!anySearch) continue;
         if (int rc = hm_encode_planes(s->d_boards, G, HM_DT_U8, s->d_u8, nullptr)) return rc;
-        if (hipMemcpy(u8planes.data(), s->d_u8, u8planes.size(), hipMemcpyDeviceToHost) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
+        // read after the search (the root_stats download is behind it on the same stream): the copy rides beside the search prologue
+        if (hipMemcpyAsync(s->h_u8, s->d_u8, u8bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
         for (int g = 0; g < G; ++g) {
             target[g] = 1; seeds[g] = 0;
             if (!mask[g]) continue;
@@ -777,7 +782,7 @@ static int selfplay_run_impl(hm_selfplay* s) {
             sm.macroPly = static_cast<uint16_t>(std::min<size_t>(sl.macroPly, 65535));
             sm.team = sl.team == HM_WHITE ? 0 : 1;
             sm.hasTimeAdvantage = sl.adv ? 1 : 0;
-            std::memcpy(sm.planes.data(), u8planes.data() + (size_t)g * HM_PLANE_VALUES, HM_PLANE_VALUES);
+            std::memcpy(sm.planes.data(), s->h_u8 + (size_t)g * HM_PLANE_VALUES, HM_PLANE_VALUES);
             uint64_t actual = 0;
             for (int i = 0; i < n; ++i) actual += (uint64_t)std::max(0, ev[i]);
             sm.nodes = static_cast<uint32_t>(std::min<uint64_t>(actual, 0xffffffffu));
