@@ -773,7 +773,11 @@ __device__ inline void path_rebuild_history(const G& s, const TrajEnt* traj, int
 }
 
 // searchthread.cc:741-806.  Returns: 0 = not expanded, 1 = expanded, 2 = pending (selection must abort).
-__device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, int parent, int idx, int& child, bool& reserved, bool rootAdv, int rootTeam, int* pendingOut) {
+// deferEdge: the edge updates (replace_child, remove_virtual_loss) are left to the caller's partner — with the LDS tree every edge
+// store of a collect phase comes from the traversal wave (collect_batch applies them when the descent is handed back): the classifier
+// and the traversal running ahead of it never write the same edge or the same node's virtual-visit sum, and the traversal need not
+// drain its edge stores before it posts a request.
+__device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, TrajEnt* traj, int parent, int idx, int& child, bool& reserved, bool rootAdv, int rootTeam, int* pendingOut, bool deferEdge) {
     Node& c0 = s.nodes[child];
     if (!s.prm->enableTranspositions) return (c0.flags & F_EXPANDED) ? 1 : 0;
     if (c0.hash != 0) return (c0.flags & F_EXPANDED) ? 1 : 0;
@@ -787,14 +791,16 @@ __device__ inline int canonicalize_child(G& s, const RulesTab& rt, Path& p, Traj
     const bool teamMismatch = s.nodes[canonical].team != c0.team;
     if (canonical == child || isAncestor || teamMismatch) return (c0.flags & F_EXPANDED) ? 1 : 0;
     if (reserved) { c0.flags &= ~F_PENDING; reserved = false; }
-    edges_of(s, s.nodes[parent])[idx].child = canonical;       // replace_child
+    if (!deferEdge) edges_of(s, s.nodes[parent])[idx].child = canonical;       // replace_child
     child = canonical;
     Node& cn = s.nodes[canonical];
     if (cn.flags & F_EXPANDED) return 1;
     if (cn.type != T_UNSOLVED) return 0;
     if (cn.flags & F_PENDING) {
-        Node& pn = s.nodes[parent];
-        edges_of(s, pn)[idx].vloss--; pn.vvsum--;             // remove_virtual_loss
+        if (!deferEdge) {
+            Node& pn = s.nodes[parent];
+            edges_of(s, pn)[idx].vloss--; pn.vvsum--;         // remove_virtual_loss
+        }
         *pendingOut = canonical;
         return 2;
     }
@@ -1304,7 +1310,7 @@ __device__ __forceinline__ void serve_leaf(G& s, const RulesTab& rt, WaveLds& L,
         p.len = len - 1;                                       // the path down to the parent (canonicalize_child's ancestor test)
         p.posNode = -1;
         if (position_child(s, rt, p, rq.parent, leaf, rq.ma, rq.mb))
-            cr = canonicalize_child(s, rt, p, trajReq, rq.parent, rq.idx, next, childReserved, rootAdv, rootTeam, &pend);
+            cr = canonicalize_child(s, rt, p, trajReq, rq.parent, rq.idx, next, childReserved, rootAdv, rootTeam, &pend, s.ldsTree);
         const bool fast = cr == 0 && next == leaf && childReserved == reserved;
         if (lane == 0) { L.createRes.fast = fast ? 1 : 0; L.createRes.cr = cr; L.createRes.next = next; L.createRes.reserved = childReserved ? 1 : 0; }
         // what the traversal reads once it knows the outcome: the result word and — only when the descent goes back to it — the
@@ -1444,6 +1450,13 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             d = dj;
             const int cr = L.createRes.cr, next = L.createRes.next;
             const bool childReserved = L.createRes.reserved != 0;
+            if (s.ldsTree && cr != 3) {                            // canonicalize_child's edge updates, left to this wave (deferEdge)
+                Node& pn = s.nodes[dj.parent];
+                Edge* e = edges_of(s, pn) + dj.idx;
+                if (next != dj.child) e->child = next;             // replace_child
+                if (cr == 2) { e->vloss--; pn.vvsum--; }           // remove_virtual_loss
+                wave_fence();
+            }
             if (cr >= 2) {                                         // pending evaluation behind the transposition (its virtual loss is already removed) / pool exhausted
                 L.traj[d.len - 1].childIdx = -1;                   // as select_and_expand leaves it when it gives up here
                 wave_fence();
@@ -1531,9 +1544,14 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             const int rslot = (s.reqSeq + 1) & 1;
             for (int i = lane; i < d.len; i += 64) L.trajReq[rslot][i] = L.traj[i];
             if (lane == 0) L.req[rslot] = WaveLds::Req{leaf, d.len, nctx, buf, reserved ? 1 : 0, posted ? 0 : 1, create ? 1 : 0, d.parent, d.idx, d.ma, d.mb};
-            wave_fence();
             s.reqSeq++;
-            if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (s.ldsTree) {                                       // the classifier reads LDS only of what this wave wrote in this phase (request, path, nodes;
+                lds_release();                                     // the edges are this wave's alone: canonicalize_child's deferEdge): no drain of the edge stores
+                if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                wave_fence();
+                if (lane == 0) __hip_atomic_store(&L.reqSeq, s.reqSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             s.inflight = leaf; s.svcBusy = true;
             posted = true;
             if (create) { s.jPending = true; jSlot = rslot; }
@@ -1551,7 +1569,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
         }
         if (keep) {
             if (lane == 0) L.batchLeaf[nctx] = leaf;
-            wave_fence();
+            wave_sync();                                           // read by this wave's collision test; by others after the phase's barrier
             nctx++;
         }
     }
