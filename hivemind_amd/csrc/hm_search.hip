@@ -1961,6 +1961,8 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     __shared__ SearchCtl s_ctl;
     __shared__ unsigned s_expect[2];                                // rows published per buffer so far
     __shared__ PubCtx s_pub;
+    constexpr int HIST_LDS = 512;
+    __shared__ u64 s_hist[2][HIST_LDS];                             // G::hist of this game (see below)
     const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     PROF_INIT();
     G s = make_view(pl, prm, g);
@@ -1994,6 +1996,16 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     s.g = &s_game;
     s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
     if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
+    // The game's repetition keys (read by every draw test and hash of the classifier wave, with the search path's keys rebuilt behind
+    // them per leaf: path_rebuild_history) in LDS when the game's history and the longest path fit; nothing to write back — the search
+    // only appends scratch behind the game's own keys.
+    if (s_game.hlen[0] + MAX_TRAJ + 8 <= HIST_LDS && s_game.hlen[1] + MAX_TRAJ + 8 <= HIST_LDS) {
+        for (int b = 0; b < 2; ++b) {
+            for (int i = threadIdx.x; i < s_game.hlen[b]; i += COLLECT_THREADS) s_hist[b][i] = s.hist[b][i];
+            s.hist[b] = s_hist[b];
+        }
+        __syncthreads();
+    }
     const int rootTeam = s_game.team;
     const bool rootAdv = s_game.adv != 0;
     const int rowBase = g * BATCH;
