@@ -225,6 +225,8 @@ void ora_search_info(void* sp, int* out /*8*/) {
     out[4] = s->reservationCollisions; out[5] = s->nodeCounter; out[6] = s->root ? (int)s->root->nodeType : -1;
     out[7] = s->root ? s->root->visits : 0;
 }
+// lookups that found their position in the transposition table (insertOrGet, transposition_table.h:83-103)
+int ora_search_tt_hits(void* sp) { return static_cast<Search*>(sp)->ttHits; }
 int ora_search_trace(void* sp, uint64_t* out, int cap) {
     Search* s = static_cast<Search*>(sp);
     int n = (int)std::min<size_t>(s->evalTrace.size(), (size_t)cap);

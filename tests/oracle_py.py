@@ -175,6 +175,7 @@ def policy_tables(impl="ora"):
 lib.ora_search_new.restype, lib.ora_search_new.argtypes = _vp, [_i, _i]
 lib.ora_search_free.restype, lib.ora_search_free.argtypes = None, [_vp]
 lib.ora_search_set_noise.restype, lib.ora_search_set_noise.argtypes = None, [_vp, C.c_float, C.c_float, _u64]
+lib.ora_search_tt_hits.restype, lib.ora_search_tt_hits.argtypes = _i, [_vp]
 lib.ora_search_set_transpositions.restype, lib.ora_search_set_transpositions.argtypes = None, [_vp, _i]
 lib.ora_search_run.restype, lib.ora_search_run.argtypes = _i, [_vp, _vp, _i, _i, _i]
 lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]
@@ -257,6 +258,7 @@ class Search:
         return dict(nodes=int(o[0]), eval_rows=int(o[1]), eval_calls=int(o[2]), same_batch=int(o[3]),
                     reservation=int(o[4]), node_count=int(o[5]), root_type=int(o[6]), root_visits=int(o[7]))
 
+    def tt_hits(self): return int(lib.ora_search_tt_hits(self.h))
     def root_q(self): return float(lib.ora_search_root_q(self.h))
     def best_move(self): return int(lib.ora_search_best_move(self.h))
 

@@ -177,3 +177,90 @@ def test_search_at_the_lds_mirror_boundary(hm, nodes):
         e = s.edges()
         n = st["counts"][g]
         assert st["info"][g][8] == 0 and n == len(e["visits"]) and np.array_equal(st["visits"][g, :n], e["visits"]), g
+
+
+# Blocked-pawn king endings: two or three legal moves per board, so a few hundred nodes reach depth 6+ and the same joint position
+# comes up along several move orders (5-36 transposition-table hits per search, up to 1 300 same-batch collisions and 140
+# reservation collisions) — random middle-game roots give none at these budgets.  Exercises canonicalize_child's replace_child /
+# pending-evaluation outcomes (searchthread.cc:741-806): on the GPU the descent that ran ahead is cancelled, the edge updates are
+# applied by the traversal wave and the handed-back descent continues (collect_batch).
+_TRANSPOSING = [("k7/p7/P7/8/8/8/8/7K[] w - - 0 1", "7k/8/8/8/8/p7/P7/K7[] b - - 0 1"),
+                ("k7/p7/P7/8/8/7p/7P/7K[] w - - 0 1", "k7/p7/P7/8/8/7p/7P/7K[] b - - 0 1"),
+                ("k7/p7/P7/8/8/7p/7P/7K[] w - - 0 1", "k7/p7/P7/8/8/7p/7P/7K[] w - - 0 1")]
+
+
+def _transposing_roots():
+    rows = []
+    for fa, fb in _TRANSPOSING:
+        for adv in (False, True):
+            for team in (0, 1):
+                b = O.Board()
+                b.set_fen(0, fa)
+                b.set_fen(1, fb)
+                rows.append(b.compact(team, adv))
+    return np.concatenate(rows)
+
+
+@pytest.mark.parametrize("nodes", [400, 1600])
+def test_search_with_many_transpositions_matches_oracle(hm, nodes):
+    roots = _transposing_roots()
+    G = len(roots)
+    eng = hm.SearchEngine(G, 1700)
+    eng.set_games(roots)
+    eng.begin_search(nodes, None, 0.0, 0.0)
+    eng.run(_hash_eval_gpu)
+    st = eng.root_stats()
+    hits = collisions = searched = 0
+    for g in range(G):
+        b = O.Board()
+        b.from_compact(roots[g:g + 1])
+        s = O.Search(1, 1)
+        ok = s.run(b, int(roots["team"][g]), bool(roots["time_adv"][g]), nodes)
+        info = st["info"][g]
+        if not ok:
+            assert info[0] == 4, (g, info)
+            continue
+        searched += 1
+        e, oi, n = s.edges(), s.info(), st["counts"][g]
+        assert info[8] == 0, ("overflow", g, info)
+        assert n == len(e["visits"]), (g, n, len(e["visits"]))
+        for k in ("move_a", "move_b", "visits", "prior", "q"):
+            assert np.array_equal(st[k][g, :n], e[k]), (g, k, st[k][g, :n], e[k])
+        assert (info[1], info[2], info[3], info[4], info[5]) == (oi["nodes"], oi["eval_rows"], oi["same_batch"], oi["reservation"], oi["node_count"]), (g, info, oi)
+        assert info[18] == s.tt_hits(), (g, info[18], s.tt_hits())
+        assert st["root_q"][g] == np.float32(s.root_q())
+        assert info[12] == s.best_move()
+        hits += int(info[18]); collisions += int(info[3]) + int(info[4])
+    assert searched >= 8 and hits >= (40 if nodes == 400 else 150) and collisions > 500, (searched, hits, collisions)
+    eng.close()
+
+
+def test_persistent_search_with_many_transpositions_equals_lockstep(hm):
+    """the same roots through k_search + rise_serve (creation on the classifier wave, hand-backs, deferred edge updates) and through
+    the lockstep kernels, with a network as evaluator: identical root statistics and counters, transposition hits included"""
+    import torch
+    from hivemind_amd import net as N
+    torch.manual_seed(0)
+    net = N.FusedNet(N.rise_v3_small())
+    roots = _transposing_roots()
+    G = len(roots)
+    for nodes, cap in ((400, 421), (1600, 1700)):                   # LDS tree / tree walked in place
+        eng = hm.SearchEngine(G, cap)
+        eng.set_games(roots)
+        eng.begin_search(nodes, None, 0.0, 0.0)
+        eng.run(net)
+        want = eng.root_stats()
+        eng.set_games(roots)
+        eng.begin_search(nodes, None, 0.0, 0.0)
+        assert eng.search_persistent(net) > 0.0
+        got = eng.root_stats()
+        for g in range(G):
+            n = want["counts"][g]
+            assert n == got["counts"][g], g
+            for k in ("move_a", "move_b", "visits"):
+                assert np.array_equal(want[k][g, :n], got[k][g, :n]), (g, k)
+            for k in ("q", "prior"):
+                assert np.array_equal(want[k][g, :n].view(np.uint32), got[k][g, :n].view(np.uint32)), (g, k)
+            assert np.array_equal(want["info"][g, :20], got["info"][g, :20]), (g, want["info"][g], got["info"][g])
+        assert int(want["info"][:, 18].sum()) > 0
+        eng.close()
