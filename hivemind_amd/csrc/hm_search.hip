@@ -58,6 +58,7 @@ namespace hms {
 
 constexpr int BATCH = 8;                 // SearchParams::BATCH_SIZE
 constexpr int MAX_TRAJ = 96;             // search path cap (root .. leaf)
+constexpr int SEARCH_HIST_LDS = 1024 + MAX_TRAJ + 8;   // k_search<true>: history keys per board it keeps in LDS (Params::histCap of the default game length)
 constexpr int HIST_GAME_MIN = 1024;      // game history keys per board (grown to the run's macro-ply limit, hm_sp_create_ex)
 constexpr int NOISE_CAP = hmp::NOISE_CAP; // > max actions per board (304 + pass)
 constexpr int MIN_VISITS_TAB = 1 << 15;  // cpuct / PW tables: at least this long; sized from the node budget (Params::tabLen)
@@ -1948,6 +1949,10 @@ __device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L
     for (int i = wave - 1; i < nctx; i += 3) expand_context(s, rt, L, pending, i, rootTeam, rootAdv, out, rowBase, pre);
 }
 
+// LDS_TREE: the node pool is the LDS mirror — a template parameter, not a launch-time flag, so that `s.nodes` is known to be an LDS
+// address in that instantiation: every node access compiles to a ds_ instruction instead of a flat_ one (a flat access waits on BOTH
+// memory counters, i.e. also for the wave's outstanding global stores — the virtual-loss store of the level above).
+template <bool LDS_TREE>
 __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm, SearchIo io) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_nodes[];
     __shared__ RulesTab s_rt;
@@ -1961,8 +1966,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     __shared__ SearchCtl s_ctl;
     __shared__ unsigned s_expect[2];                                // rows published per buffer so far
     __shared__ PubCtx s_pub;
-    constexpr int HIST_LDS = 512;
-    __shared__ u64 s_hist[2][HIST_LDS];                             // G::hist of this game (see below)
+    __shared__ u64 s_hist[LDS_TREE ? 2 : 1][LDS_TREE ? SEARCH_HIST_LDS : 1];                             // G::hist of this game (see below)
     const int g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     PROF_INIT();
     G s = make_view(pl, prm, g);
@@ -1984,7 +1988,7 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
         if (threadIdx.x == 0) { __hip_atomic_fetch_add(hmq::G32(&io.q->treesOut), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); hmq::producer_exit(io.q); }
         return;
     }
-    const bool mirror = io.ldsNodes != 0;
+    constexpr bool mirror = LDS_TREE;                               // (io.ldsNodes says the same: the host picks the instantiation)
     if (mirror) {
         const int words = s_game.nodeCount * 4;
         const uint4* src = reinterpret_cast<const uint4*>(gNodes);
@@ -1995,12 +1999,13 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_search(Pools pl, Params prm
     }
     s.g = &s_game;
     s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
-    if (wave == 0) { s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq; }
+    // (every wave: pointers that depend on the wave index compile to flat accesses; only the traversal wave uses them)
+    s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast; s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq;
     // The game's repetition keys (read by every draw test and hash of the classifier wave, with the search path's keys rebuilt behind
     // them per leaf: path_rebuild_history) in LDS when the game's history and the longest path fit; nothing to write back — the search
     // only appends scratch behind the game's own keys.
-    if (s_game.hlen[0] + MAX_TRAJ + 8 <= HIST_LDS && s_game.hlen[1] + MAX_TRAJ + 8 <= HIST_LDS) {
-        for (int b = 0; b < 2; ++b) {
+    if constexpr (LDS_TREE) {                                       // (unconditional: a pointer that may be either compiles to flat accesses; hm_sp_create_ex
+        for (int b = 0; b < 2; ++b) {                               //  admits this instantiation only when Params::histCap fits SEARCH_HIST_LDS)
             for (int i = threadIdx.x; i < s_game.hlen[b]; i += COLLECT_THREADS) s_hist[b][i] = s.hist[b][i];
             s.hist[b] = s_hist[b];
         }
@@ -3301,11 +3306,11 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
         rc |= dalloc(sp, &sp->d_queue, sp->queueBytes);
         hipFuncAttributes fa;
         size_t staticLds = 64 * 1024;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_search)) == hipSuccess) staticLds = fa.sharedSizeBytes;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_search<true>)) == hipSuccess) staticLds = fa.sharedSizeBytes;
         else (void)hipGetLastError();
         const size_t room = staticLds < 160 * 1024 ? 160 * 1024 - staticLds : 0;
-        sp->searchLdsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
-        if (sp->searchLdsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) != hipSuccess) {
+        sp->searchLdsNodes = ((size_t)p.nodeCap * sizeof(Node) <= room && p.histCap <= SEARCH_HIST_LDS && !std::getenv("HM_SEARCH_NO_LDS_NODES")) ? 1 : 0;
+        if (sp->searchLdsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) != hipSuccess) {
             (void)hipGetLastError();
             sp->searchLdsNodes = 0;
         }
@@ -3612,7 +3617,8 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     sio.q = q; sio.done = done; sio.progress = done + (size_t)sp->nGames * 2; sio.netSel = nullptr; sio.ldsNodes = sp->searchLdsNodes;
     (void)hipEventRecord(sp->evT0, sT);            // HIP events on the stream the kernel is launched on: its launch duration
     if (perWg > 1) hipLaunchKernelGGL(k_search_mg, dim3(searchWgs), dim3(COLLECT_THREADS), 0, sT, sp->pl, sp->prm, sio, sp->nGames, perWg);
-    else hipLaunchKernelGGL(k_search, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->searchLdsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, sT, sp->pl, sp->prm, sio);
+    else if (sp->searchLdsNodes) hipLaunchKernelGGL(k_search<true>, dim3(sp->nGames), dim3(COLLECT_THREADS), (size_t)sp->prm.nodeCap * sizeof(Node), sT, sp->pl, sp->prm, sio);
+    else hipLaunchKernelGGL(k_search<false>, dim3(sp->nGames), dim3(COLLECT_THREADS), 0, sT, sp->pl, sp->prm, sio);
     const hipError_t le = hipGetLastError();
     (void)hipEventRecord(sp->evT1, sT);
     if (le != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, std::string("k_search launch failed: ") + hipGetErrorString(le));
