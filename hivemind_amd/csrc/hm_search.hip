@@ -1803,6 +1803,8 @@ __device__ __forceinline__ void collect_helper_role(G& s, const RulesTab& s_rt, 
 // whole node pool (64 B per node: 88 KB at nodes = 400) and its Game record into LDS with wide coalesced loads, walks the
 // tree there, and writes both back at the end; edges, generator blocks and the transposition table stay in HBM/L2.
 // Searches whose pool does not fit (prm.ldsNodes == 0) walk the pool in place.
+// MIRROR (the node pool in LDS for the launch): a template parameter for the reason given at k_search
+template <bool MIRROR>
 __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params prm, uint16_t* planesNext, int* rowsNext, int* activeCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *activeCount = 0;     // k_process of this iteration re-counts
     if (threadIdx.x == 0) {
@@ -1844,9 +1846,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     __syncthreads();
     const bool searching = s_game.status == ST_SEARCHING;
     const int startCount = s_game.nodeCount;                       // nodes with a higher id are created by this launch
-    const bool mirror = prm.ldsNodes != 0 && searching;
+    constexpr bool mirror = MIRROR;
     if (mirror) {
-        const int words = s_game.nodeCount * 4;                    // uint4 words
+        const int words = searching ? s_game.nodeCount * 4 : 0;    // uint4 words (an idle / finished game touches no node)
         const uint4* src = reinterpret_cast<const uint4*>(gNodes);
         uint4* dst = reinterpret_cast<uint4*>(s_nodes);
         for (int i = threadIdx.x; i < words; i += COLLECT_THREADS) dst[i] = src[i];
@@ -1858,9 +1860,9 @@ __global__ __launch_bounds__(COLLECT_THREADS) void k_collect(Pools pl, Params pr
     s.ldsCpuct = s_cpuct; s.ldsPwRoot = s_pwRoot; s.ldsPwNode = s_pwNode; s.tabN = TABN;
     PROF_ADD(9, ta);
     const int wave = threadIdx.x >> 6;
+    s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast;
+    s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq;
     if (wave == 0) {
-        s.ackSeq = &L.ackSeq; s.typeSeq = &L.typeSeq; s.createSeq = &L.createSeq; s.createFast = &L.createRes.fast;
-        s.gq = &L.gq; s.genAckSeq = &L.gq.ackSeq;
         const int rows = collect_step(s, s_rt, L, planesNext, blockIdx.x);
         if (threadIdx.x == 0) {
             s_game.nodesVisited += s.nv; s_game.edgesScanned += s.es;
@@ -3200,7 +3202,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
         // the node mirror shares the CU's 160 KB of LDS with k_collect's static LDS (tables, wave scratch, request slots)
         hipFuncAttributes fa;
         size_t staticLds = 48 * 1024;
-        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_collect)) == hipSuccess) staticLds = fa.sharedSizeBytes;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_collect<true>)) == hipSuccess) staticLds = fa.sharedSizeBytes;
         else (void)hipGetLastError();
         const size_t room = staticLds < 160 * 1024 ? 160 * 1024 - staticLds : 0;
         // (s_dirty in k_collect holds LDS_DIRTY_BITS node bits: pools beyond that walk their nodes in place)
@@ -3217,7 +3219,7 @@ int hm_sp_create_ex(int n_games, int max_nodes, int max_game_plies, const hm_sea
     p.qVetoDelta = 0.4f; p.qValueWeight = 1.0f;
     // the attribute is per-function process state: always the largest mirror the CU admits, so that a second, smaller engine does
     // not lower the limit under an engine that is still alive
-    if (p.ldsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->ldsMirrorMax) != hipSuccess) {
+    if (p.ldsNodes && hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp->ldsMirrorMax) != hipSuccess) {
         (void)hipGetLastError();
         p.ldsNodes = 0;                                            // walk the pool in place
     }
@@ -3494,8 +3496,10 @@ int hm_sp_search_stalled(const hm_sp* sp) { return sp && sp->lastQueueError == 5
 int hm_sp_search_lds_tree(const hm_sp* sp) { return sp && sp->searchLdsNodes ? 1 : 0; }
 int hm_sp_collect_counted(hm_sp* sp, void* d_planes_next, int32_t* d_rows_next, void* stream) {
     if (!sp || !d_planes_next) return hm_fail(HM_ERR_INVALID, "null argument");
-    hipLaunchKernelGGL(k_collect, dim3(sp->nGames), dim3(COLLECT_THREADS), sp->prm.ldsNodes ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
-                       static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
+    if (sp->prm.ldsNodes) hipLaunchKernelGGL(k_collect<true>, dim3(sp->nGames), dim3(COLLECT_THREADS), (size_t)sp->prm.nodeCap * sizeof(Node), static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+                                             static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
+    else hipLaunchKernelGGL(k_collect<false>, dim3(sp->nGames), dim3(COLLECT_THREADS), 0, static_cast<hipStream_t>(stream), sp->pl, sp->prm,
+                            static_cast<uint16_t*>(d_planes_next), d_rows_next, sp->d_active);
     HIPCHK(hipGetLastError());
     return 0;
 }
