@@ -324,6 +324,16 @@ class SelfPlayOracle:
         except Exception:
             pass
 
+    def set_evaluator(self, fn):
+        """fn(planes uint16 [n,4736]) -> (value[n], piA[n,4672], piB[n,4672], wdl[n,3], ml[n]) uint16 arrays (as Search.set_evaluator)."""
+        def cb(planes, n, value, pia, pib, wdl, ml):
+            pl = np.ctypeslib.as_array(C.cast(planes, C.POINTER(C.c_uint16)), shape=(n, 4736))
+            v, a, b, w, m = fn(pl)
+            for dst, src, cnt in ((value, v, n), (pia, a, n * 4672), (pib, b, n * 4672), (wdl, w, n * 3), (ml, m, n)):
+                C.memmove(dst, np.ascontiguousarray(src, dtype=np.uint16).ctypes.data, 2 * cnt)
+        self._cb = EVAL_CB(cb)
+        lib.ora_selfplay_set_callback(self.h, self._cb)
+
     def game(self, index):
         """-> (record bytes of the game, dict(samples, raw_plies, winner, termination, nodes), actions [(moveA, moveB, raw)])"""
         cap = 1 << 22
