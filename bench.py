@@ -132,7 +132,8 @@ def _pmc_traffic(path):
 
 
 _PMC_ALGO = {}                 # per summary file: algorithmic bytes per launch of the profiled command's own phase (tools/run_selfplay.py)
-PMC_SELFPLAY = "profiles/r03_selfplay64_pmc_hbm.json"
+PMC_SELFPLAY = "profiles/r04_selfplay64_pmc_hbm.json"                 # the single-launch search (k_rollout) under rocprofv3 --pmc
+PMC_LOCKSTEP = "profiles/r04_selfplay64_lockstep_pmc_hbm.json"       # the lockstep kernels (HM_SELFPLAY_LOCKSTEP=1)
 PMC_PLANES = "profiles/r03_planes_pmc_hbm.json"
 
 
@@ -325,15 +326,16 @@ def main():
         persistent = tot["searches"] > 0
         pmc = _pmc_traffic(PMC_SELFPLAY) if (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
         if persistent:
-            # Persistent search (hm_sp_search): ONE launch of k_search (a workgroup per game) beside ONE launch of rise_serve (the
-            # evaluator workgroups) per searched ply; both last as long as the ply's slowest game.  `kernel_ms` = average k_search
-            # launch, HIP events on the stream it is launched on (hm_sp_search).  Legs are per game-iteration (device clock).
+            # Single-launch search (hm_sp_search): ONE launch of k_rollout per searched ply — its first workgroups are the games (one
+            # workgroup per game for the whole search), the others the evaluator (one position per workgroup at a time); it lasts as long
+            # as the ply's slowest game.  `kernel_ms` = average launch, HIP events on the stream it is launched on (hm_sp_search).
+            # Legs are per game-iteration (device clock).
             launches = tot["searches"]
             ks_ms = tot["search_kernel_ms"] / launches
-            legs = {"k_search: collect phase (tree traversal)": tot["collect_ms"] / it, "k_search: wait for the evaluator": tot["wait_ms"] / it,
-                    "k_search: process phase (expand+backup)": tot["process_ms"] / it,
-                    "rise_serve: per position (one workgroup)": tot["eval_ms"] / max(tot["eval_rows"], 1)}
-            dominant = "k_search"
+            legs = {"k_rollout search role: collect phase (tree traversal)": tot["collect_ms"] / it, "k_rollout search role: wait for the evaluator": tot["wait_ms"] / it,
+                    "k_rollout search role: process phase (expand+backup)": tot["process_ms"] / it,
+                    "k_rollout evaluator role: per position (one workgroup)": tot["eval_ms"] / max(tot["eval_rows"], 1)}
+            dominant = "k_rollout"
             # HBM bytes the search needs per launch: the node pool stays in LDS for the whole search (loaded and written back once:
             # counted with the position records), so per visited path node only its edge record is scanned / updated in HBM (40 B each),
             # per created node a 232-byte position record is written and read back at the leaf, per network leaf the 9472-byte fp16
@@ -341,32 +343,43 @@ def main():
             by = (tot["es"] * 40 + tot["nv"] * 40 + tot["nodes"] * 2 * 232 + tot["eval_rows"] * 9472 + tot["lw"] * 12) / launches
             ach = by / (ks_ms * 1e-3) / 1e9
             roof_tree = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_search (persistent search: one workgroup per game for a whole search)", "kernel_ms": ks_ms,
+                         "kernel": "k_rollout (single-launch search: game workgroups + evaluator workgroups, hm_rollout.hip)", "kernel_ms": ks_ms,
                          "algorithmic_bytes_per_launch": by, "launches": launches,
                          "note": "latency-bound: a game's descents are a chain of dependent LDS / L2 reads on one wavefront; a launch lasts as long "
-                                 "as its slowest game's search; see DESIGN.md",
-                         "traffic_source": "none: rocprofv3 --pmc runs kernels one at a time, which the two persistent kernels cannot do; the lockstep "
-                                           "kernels' counters (HM_SELFPLAY_LOCKSTEP=1) are kept under profiles/ and in extra.lockstep_pmc_traffic"}
+                                 "as its slowest game's search; the algorithmic bytes are the TREE's — the evaluator role's weight stream "
+                                 "(2 MB per position out of L2 for RISEv3-small) is the counters' excess; see DESIGN.md"}
+            tr = [v for k, v in pmc.items() if "k_rollout" in k]
+            if tr:
+                roof_tree["traffic"] = sum(tr)
+                same = (_PMC_ALGO.get(PMC_SELFPLAY) or {}).get("k_rollout")
+                if same:
+                    roof_tree["algorithmic_bytes_per_launch_same_phase"] = same
+                    roof_tree["traffic_over_algorithmic_same_phase"] = roof_tree["traffic"] / same
+                roof_tree["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload's first 30 macro-plies on these kernel sources)"
+            else:
+                roof_tree["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"
             fl = tot["eval_rows"] * flops / launches
             ach = fl / (ks_ms * 1e-3) / 1e12
             busy_ms = tot["eval_ms"] / max(tot["eval_rows"], 1)
             roof_net = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "rise_serve (persistent evaluator: one position per workgroup at a time)", "kernel_ms": ks_ms,
+                        "kernel": "k_rollout evaluator role (one position per workgroup at a time)", "kernel_ms": ks_ms,
                         "algorithmic_flops_per_launch": fl, "rows_per_launch": tot["eval_rows"] / launches, "busy_ms_per_position": busy_ms,
                         "TFLOPs_of_one_busy_workgroup": flops / (busy_ms * 1e-3) / 1e12,
                         "note": "launch duration = the search's; the evaluator idles whenever the games have no batch for it",
                         "traffic_source": roof_tree["traffic_source"]}
-            if pmc:
-                same = _PMC_ALGO.get(PMC_SELFPLAY) or {}
+            lock = _pmc_traffic(PMC_LOCKSTEP) if pmc else {}
+            if lock:
+                same = _PMC_ALGO.get(PMC_LOCKSTEP) or {}
                 cmp_ = {}
                 for key in ("k_collect", "rise_forward"):
-                    hit = [k for k in pmc if key in k]
+                    hit = [k for k in lock if key in k]
                     if hit and same.get(key):
-                        tr = sum(pmc[k] for k in hit)
-                        cmp_[key] = {"traffic_bytes_per_launch": tr, "algorithmic_bytes_per_launch_same_phase": same[key], "ratio": tr / same[key]}
-                extra["lockstep_pmc_traffic"] = {"source": PMC_SELFPLAY, "bytes_per_launch": pmc, "same_phase": cmp_,
+                        trl = sum(lock[k] for k in hit)
+                        cmp_[key] = {"traffic_bytes_per_launch": trl, "algorithmic_bytes_per_launch_same_phase": same[key], "ratio": trl / same[key]}
+                extra["lockstep_pmc_traffic"] = {"source": PMC_LOCKSTEP, "bytes_per_launch": lock, "same_phase": cmp_,
                                                  "note": "counters and algorithmic bytes both over the profiled command (first 30 macro-plies, all games alive, lockstep kernels)"}
         else:
+            pmc = _pmc_traffic(PMC_LOCKSTEP) if pmc is not None and (args.games == 64 and args.nodes == 400 and args.model == "small") else {}
             legs = {"k_collect (tree traversal)": tot["collect_ms"] / it, "RISEv3 forward (net)": tot["eval_ms"] / it,
                     "k_process (expand+backup)": tot["process_ms"] / it}
             dominant = max(legs, key=legs.get)
@@ -391,15 +404,15 @@ def main():
                 hit = [k for k in pmc if key in k]
                 if hit:
                     r_["traffic"] = sum(pmc[k] for k in hit)
-                    same = (_PMC_ALGO.get(PMC_SELFPLAY) or {}).get("k_collect" if key == "k_collect" else "rise_forward")
+                    same = (_PMC_ALGO.get(PMC_LOCKSTEP) or {}).get("k_collect" if key == "k_collect" else "rise_forward")
                     if same:                   # both numbers over the profiled command's own phase (the run's average launch is thinner)
                         r_["algorithmic_bytes_per_launch_same_phase"] = same
                         r_["traffic_over_algorithmic_same_phase"] = r_["traffic"] / same
-                    r_["traffic_source"] = PMC_SELFPLAY + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
+                    r_["traffic_source"] = PMC_LOCKSTEP + " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this workload on these kernel sources)"
                 else:
                     r_["traffic_source"] = "no PMC summary for these kernel sources (tools/pmc_summary.py refuses stale profiles)"
         roof = roof_net if dominant.startswith("RISEv3") else roof_tree
-        extra["search_mode"] = "persistent (k_search + rise_serve, hm_queue.hpp)" if persistent else "lockstep (k_collect || forward -> k_process)"
+        extra["search_mode"] = "single launch (k_rollout: game + evaluator workgroups, hm_queue.hpp)" if persistent else "lockstep (k_collect || forward -> k_process)"
         extra["rooflines"] = [roof_tree, roof_net]
         extra["selfplay"] = {"samples": samples, "nodes": nodes, "nodes_per_s": nodes / dt, "games": tot["games"] * world,
                              "iterations": tot["iters"], "iteration_unit": "game-iterations (per game: collect -> process)" if persistent else "lockstep iterations (all games)",
@@ -407,6 +420,7 @@ def main():
                              "eval_rows": tot["eval_rows"], "record_bytes_rank0": tot["bytes"], "net_gflop_per_position": flops / 1e9,
                              "persistent_searches": tot["searches"], "search_kernel_ms_total": tot["search_kernel_ms"], "wait_ms_total": tot["wait_ms"],
                              "persistent_searches_repeated_after_a_stall": tot["stalls"],
+                             "legs_mix_two_loops": bool(tot["stalls"]),     # a search the hang guard gave up was repeated on the lockstep loop: its iterations / leg times are lockstep ones
                              "transposition_table": {"lookups_that_hit": tot["tt_hits"], "inserts": tot["tt_inserts"],
                                                      "hit_rate": tot["tt_hits"] / max(tot["tt_hits"] + tot["tt_inserts"], 1)},
                              "wall_split_s": {"run": tot["seconds"], "search": tot["search_s"], "prologue": tot["prologue_s"], "raw_policy": tot["raw_s"]}}

@@ -1,7 +1,7 @@
-// hm_queue.hpp — device-side evaluation queue between the persistent search kernel (k_search, hm_search.hip: one workgroup per
-// game, alive for a whole search) and the persistent evaluator kernel (rise_serve, hm_net.hip: one workgroup per position at a
-// time), replacing the host-driven lockstep of Engine::enqueueInferenceHalf / synchronizeInferenceHalf (nn/engine.h:43-81) inside
-// SearchThread::run_iteration (searchthread.cc:661-739) for the native evaluator.
+// hm_queue.hpp — device-side evaluation queue between the search workgroups and the evaluator workgroups of the single-launch
+// search (hm_rollout.hip: k_rollout — roles by blockIdx: the first workgroups are games, alive for a whole search, the others
+// evaluate one position at a time), replacing the host-driven lockstep of Engine::enqueueInferenceHalf /
+// synchronizeInferenceHalf (nn/engine.h:43-81) inside SearchThread::run_iteration (searchthread.cc:661-739) for the native evaluator.
 //
 // Why: in the lockstep form every iteration of every game waits for the slowest game's collect and for one forward launch over all
 // games; with the queue a game's chain collect(k+1) -> [eval(k) done?] -> process(k) advances at its own pace and the evaluator
@@ -24,14 +24,15 @@ namespace hmq {
 typedef unsigned long long u64q;
 constexpr int QCAP = 8192;                   // ring slots (power of two) >> rows in flight (16 per game) + idle consumers
 constexpr u64q SPIN_LIMIT_TICKS = 2000000000ULL;   // 20 s of the 100 MHz s_memrealtime counter: a hang guard, not a schedule
-constexpr u64q MEET_LIMIT_TICKS = 300000000ULL;    // 3 s: by then the other kernel of the pair must have started (error 4: not concurrent)
-// When NO row has been published for this long (the tail has not moved) while search workgroups are still running, a waiting
-// evaluator workgroup declares the search stalled (error 5): a game's collect phase lasts ~0.1 ms, so even one live game moves
-// the tail several times per millisecond (a workgroup far back in the line may itself wait much longer for its turn).  Observed on
-// MI355X with the deployed network about once in 800 searches: the search workgroups stop making progress (in whatever phase they
-// are in, all published rows evaluated, every counter consistent) until the evaluator kernel has left the device; the caller then
-// repeats that search (hm_sp_search_stalled / hm_sp_begin_again), which costs one search and changes no result.
-constexpr u64q IDLE_LIMIT_TICKS = 3000000ULL;      // 30 ms
+constexpr u64q MEET_LIMIT_TICKS = 300000000ULL;    // 3 s: by then a workgroup of the other role must have started (error 4: the roles are not resident together)
+// Hang guard.  Every search workgroup bumps SrvQueue::beats at each phase change (collecting / collected / waiting / processing: four
+// times per game-iteration, i.e. at least every few milliseconds even in the deepest tree).  An evaluator workgroup that has seen
+// NEITHER the queue tail NOR the beat counter move for this long while search workgroups are still in declares the search stalled
+// (error 5) after taking a snapshot of every game's diagnostics record; the caller repeats that search (hm_sp_search_stalled /
+// hm_sp_begin_again), which changes no result.  (Round 3 watched the tail alone: a game deep in a forced line publishes no row for
+// tens of milliseconds — every batch is one terminal leaf plus fifteen same-batch collisions — while it is making progress all the
+// time; those alarms were false)
+constexpr u64q IDLE_LIMIT_TICKS = 5000000ULL;      // 50 ms
 
 // item payload (low 32 bits of a slot): game slot, plane buffer, row, evaluator-specific flags
 constexpr unsigned IT_POISON = 0x80000000u;  // no more work: the consumer leaves
@@ -42,18 +43,47 @@ __host__ __device__ inline int item_buf(unsigned it) { return (int)((it >> 20) &
 __host__ __device__ inline int item_row(unsigned it) { return (int)((it >> 21) & 7u); }
 __host__ __device__ inline int item_net(unsigned it) { return (int)((it >> 24) & 1u); }
 
+// Per-game diagnostics record (global memory behind the queue; written by thread 0 of the game's workgroup with write-through
+// stores, read by the host after a give-up and, for the snapshot, by the evaluator workgroup that gives up).
+struct GameDiag {
+    unsigned phase;                          // 1 collecting, 2 collected, 3 waiting for the evaluator, 4 processing, 5 the wait failed | XCC id << 4 | iteration << 8
+    unsigned stamp;                          // when `phase` was written (10 us units of s_memrealtime)
+    unsigned left;                           // when the game left the kernel (same unit), 0 = still in
+    unsigned published;                      // rows it has published so far (both buffers)
+    unsigned waitBuf;                        // 1 + the buffer whose evaluation it is waiting for (0: not waiting)
+    unsigned waitExpect;                     // rows of that buffer that must be done
+    unsigned hwId;                           // HW_REG_HW_ID of the traversal wave (SE / CU / SIMD it runs on)
+    unsigned pad;
+};
+// [SrvQueue | done[2G] | diag[G] | snapDone[2G] | snapDiag[G] | snapTime (16 B) | heartbeats[4G] (diagnostic builds)], all 16-byte aligned
+struct QueueLayout {
+    size_t done, diag, snapDone, snapDiag, snapTime, hb, bytes;
+    __host__ __device__ explicit QueueLayout(unsigned G, size_t queueStructBytes) {
+        auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        done = queueStructBytes;
+        diag = up(done + (size_t)G * 8);
+        snapDone = diag + (size_t)G * sizeof(GameDiag);
+        snapDiag = up(snapDone + (size_t)G * 8);
+        snapTime = snapDiag + (size_t)G * sizeof(GameDiag);
+        hb = snapTime + 16;
+        bytes = up(hb + (size_t)G * 16);
+    }
+};
+
 struct SrvQueue {                            // one per search engine; zeroed (whole struct) before every search
     unsigned head;                           // next ticket a consumer takes
     unsigned tail;                           // next ticket a producer fills
     unsigned producers;                      // search workgroups still running (set by the host after the memset)
     unsigned error;                          // != 0: some spin gave up (code of the first), everybody leaves
     unsigned consumers;                      // evaluator workgroups of this launch (poison count)
-    unsigned games;                          // game slots: behind the slots lie done[2G], progress[3G], heartbeats[4G] and a snapshot[7G] of the last two
+    unsigned games;                          // game slots: behind the slots lie done[2G], GameDiag[G], and a snapshot of both + its time (QueueLayout)
     unsigned served;                         // items evaluated (statistics)
     unsigned treesIn, treesOut, consIn, consOut;   // census of both kernels (diagnostics of a give-up)
     unsigned dbg[6];                         // first failed wait of a search workgroup: game, buffer, rows expected, rows done, iteration, ms since the kernel's first workgroup started
     unsigned dupTickets;                     // pushes that found their slot already carrying their own ticket's tag (diagnostics: two producers drew one ticket)
-    unsigned dbgPop[2];                      // the evaluator workgroup that gave up (error 2): its ticket, the tail and head it saw then, ms waited
+    unsigned dbgPop[2];                      // the evaluator workgroup that gave up (error 2 / 5): its ticket + 1, the tail it saw then
+    unsigned beats;                          // phase changes of all search workgroups (the hang guard's second progress signal)
+    unsigned pad_[3];
     u64q slots[QCAP];                        // {ticket + 1, payload}
 };
 static_assert(sizeof(SrvQueue) % 16 == 0, "zeroed as one block of 16-byte multiples");
@@ -112,8 +142,8 @@ __device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
     const unsigned t = __hip_atomic_fetch_add(G32(&q->head), 1u, HMQ_RLX);
     u64q* slot = &q->slots[t & (QCAP - 1)];
     const u64q t0 = __builtin_amdgcn_s_memrealtime();
-    u64q tMoved = t0;                        // when the tail was last seen to move
-    unsigned tailSeen = ~0u;
+    u64q tMoved = t0;                        // when the tail or the beat counter was last seen to move
+    unsigned tailSeen = ~0u, beatSeen = ~0u;
     for (unsigned spins = 0;; ++spins) {
         const u64q v = __hip_atomic_load(G64(slot), HMQ_RLX);
         if ((unsigned)(v >> 32) == t + 1) return (unsigned)v;
@@ -121,20 +151,25 @@ __device__ __forceinline__ unsigned pop_item(SrvQueue* q) {
         if ((spins & 255u) == 255u) {
             if (__hip_atomic_load(G32(&q->error), HMQ_RLX)) return IT_POISON;
             const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
-            // no search workgroup has started while this one has been waiting: the two kernels are being run one after the other
+            // no search workgroup has come in while this one has been waiting: the roles are not resident together
             if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(G32(&q->treesIn), HMQ_RLX) == 0u) { __hip_atomic_store(G32(&q->error), 4u, HMQ_RLX); return IT_POISON; }
-            const unsigned tailNow = __hip_atomic_load(G32(&q->tail), HMQ_RLX);
-            if (tailNow != tailSeen) { tailSeen = tailNow; tMoved = t0 + waited; }
+            const unsigned tailNow = __hip_atomic_load(G32(&q->tail), HMQ_RLX), beatNow = __hip_atomic_load(G32(&q->beats), HMQ_RLX);
+            if (tailNow != tailSeen || beatNow != beatSeen) { tailSeen = tailNow; beatSeen = beatNow; tMoved = t0 + waited; }
             const bool stalled = t0 + waited - tMoved > IDLE_LIMIT_TICKS && __hip_atomic_load(G32(&q->producers), HMQ_RLX) != 0u;
             if (stalled || waited > SPIN_LIMIT_TICKS) {
                 if (atomicCAS(&q->dbgPop[0], 0u, t + 1u) == 0u) {
-                    q->dbgPop[1] = __hip_atomic_load(G32(&q->tail), HMQ_RLX);
-                    // where every game stands NOW, before the error word lets anybody go
+                    q->dbgPop[1] = tailNow;
+                    // where every game stands NOW, before the error word lets anybody go: done counters and diagnostics records
                     const unsigned G = __hip_atomic_load(G32(&q->games), HMQ_RLX);
-                    unsigned* live = reinterpret_cast<unsigned*>(q + 1) + 2 * G;
-                    unsigned* snap = live + 7 * G;
-                    for (unsigned i = 0; i < 7 * G; ++i) snap[i] = __hip_atomic_fetch_add(G32(&live[i]), 0u, HMQ_RLX);
-                    snap[2 * G] = (unsigned)((u64q)__builtin_amdgcn_s_memrealtime() / 1000ULL);   // (slot 0's exit stamp is not needed: the time of the snapshot)
+                    const QueueLayout lay(G, sizeof(SrvQueue));
+                    unsigned char* base = reinterpret_cast<unsigned char*>(q);
+                    unsigned* liveDone = reinterpret_cast<unsigned*>(base + lay.done);
+                    unsigned* snapDone = reinterpret_cast<unsigned*>(base + lay.snapDone);
+                    for (unsigned i = 0; i < 2 * G; ++i) snapDone[i] = __hip_atomic_load(G32(&liveDone[i]), HMQ_RLX);
+                    unsigned* liveDiag = reinterpret_cast<unsigned*>(base + lay.diag);
+                    unsigned* snapDiag = reinterpret_cast<unsigned*>(base + lay.snapDiag);
+                    for (unsigned i = 0; i < G * (unsigned)(sizeof(GameDiag) / 4); ++i) snapDiag[i] = __hip_atomic_load(G32(&liveDiag[i]), HMQ_RLX);
+                    *reinterpret_cast<unsigned*>(base + lay.snapTime) = (unsigned)((u64q)__builtin_amdgcn_s_memrealtime() / 1000ULL);
                 }
                 __hip_atomic_store(G32(&q->error), stalled ? 5u : 2u, HMQ_RLX);
                 return IT_POISON;
@@ -151,7 +186,7 @@ __device__ __forceinline__ bool wait_count(SrvQueue* q, unsigned* counter, unsig
         if ((spins & 255u) == 255u) {
             if (__hip_atomic_load(G32(&q->error), HMQ_RLX)) return false;
             const u64q waited = (u64q)__builtin_amdgcn_s_memrealtime() - t0;
-            // no evaluator workgroup has started in all that time: the two kernels are being run one after the other
+            // no evaluator workgroup has come in in all that time: the roles are not resident together
             if (waited > MEET_LIMIT_TICKS && __hip_atomic_load(G32(&q->consIn), HMQ_RLX) == 0u) { __hip_atomic_store(G32(&q->error), 4u, HMQ_RLX); return false; }
             if (waited > SPIN_LIMIT_TICKS) { __hip_atomic_store(G32(&q->error), 3u, HMQ_RLX); return false; }
         }
@@ -182,14 +217,16 @@ struct ServeArgs {
     float noiseEps;
     u64q* clkSum;                            // += ticks (100 MHz) spent evaluating, or nullptr
     u64q* clkCnt;                            // += positions evaluated
+    unsigned abortAfter;                     // test hook (0 = off): once this many rows have been published an evaluator workgroup raises "stalled" — the search is given up half-way
 };
 
 }  // namespace hmq
 
 struct hm_net;
-// hm_net.hip: 1 when `net` has a persistent evaluator kernel (the 8-wave narrow trunks: C = 64, 128, 384)
+// hm_net.hip: 1 when `net` can be the evaluator of the single-launch search (the narrow trunks: C = 64, 128, 384)
 int hm_net_can_serve(const hm_net* net);
-// hm_net.hip: launches `grid` persistent evaluator workgroups on `stream`; they leave when the queue hands them IT_POISON
-int hm_net_serve(const hm_net* net, const hmq::ServeArgs& args, int grid, hipStream_t stream);
 // hm_net.hip: 1 when one position takes this network's evaluator much longer than a game needs to collect a batch (the 384-channel trunk)
 int hm_net_serve_is_slow(const hm_net* net);
+// hm_net.hip: what the evaluator role needs of a network handle
+struct hm_net_serve_info { const void* d_nd; const void* d_wh; const void* d_wf; int C, k5, copMax, uHalfs; size_t ldsBytes; };
+int hm_net_serve_info_get(const hm_net* net, hm_net_serve_info* out);

@@ -361,8 +361,8 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
         }
         harvested = upto;
     };
-    // Native evaluator, node-limited search, one network: the whole search is ONE launch of the persistent search kernel beside
-    // the persistent evaluator (hm_sp_search) — every game advances at its own pace instead of in lockstep iterations.
+    // Native evaluator, node-limited search, one network: the whole search is ONE kernel launch (hm_sp_search: game workgroups and
+    // evaluator workgroups of k_rollout) — every game advances at its own pace instead of in lockstep iterations.
     // HM_SELFPLAY_LOCKSTEP=1 keeps the host-driven loop below (the two produce identical records; tests compare them).
     if (native && !s->net2 && s->moveTimeMs <= 0 && !s->persistentOff && !std::getenv("HM_SELFPLAY_LOCKSTEP")
         && hm_sp_search_consumers(s->sp) > 0 && hm_net_can_serve(s->io.net)) {
@@ -374,14 +374,14 @@ static int run_search_lockstep(hm_selfplay* s, int minTarget) {
             return 0;
         }
         if (hm_sp_search_stalled(s->sp)) {
-            // the evaluator sat idle for 30 ms beside searching games (hm_queue.hpp: IDLE_LIMIT_TICKS): this one search is repeated
-            // from its start on the host-driven loop below — same records — and the next search is a persistent one again
+            // hang guard (hm_queue.hpp: neither the queue tail nor any game's phase moved for IDLE_LIMIT_TICKS beside searching games;
+            // hm_sp_search has printed the give-up record): this one search is repeated from its start on the host-driven loop
+            // below — same records — and the next search is a single-launch one again
             s->res.persistent_stalls += 1;
-            if (std::getenv("HM_SEARCH_DEBUG")) std::fprintf(stderr, "[hivemind_amd] stalled persistent search repeated: %s\n", hm_last_error());
         } else {
             if (!hm_sp_search_not_concurrent(s->sp)) return rc;
-            // the two persistent kernels were run one after the other (e.g. under a counter-collecting profiler): this search and
-            // all later ones of this driver take the host-driven loop
+            // the two roles of the launch were not resident together (something else holds the device's CUs): this search and all
+            // later ones of this driver take the host-driven loop
             s->persistentOff = true;
         }
         if (int rc2 = hm_sp_begin_again(s->sp)) return rc2;

@@ -170,8 +170,8 @@ class SearchEngine:
         return it
 
     def search_persistent(self, net):
-        """The whole search of every slot begin_search left searching as ONE launch of the persistent search kernel beside the
-        persistent evaluator (hm_sp_search): `net` is a FusedNet.  Same results as run(net), game by game.  -> k_search ms."""
+        """The whole search of every slot begin_search left searching as ONE kernel launch (hm_sp_search: game workgroups and
+        evaluator workgroups of k_rollout): `net` is a FusedNet.  Same results as run(net), game by game.  -> kernel ms."""
         from .selfplay import EvalIO
         f16 = dict(dtype=torch.float16, device=self.device)
         rows = self.G * BATCH
@@ -185,7 +185,16 @@ class SearchEngine:
         io.net = net.handle
         torch.cuda.synchronize(self.device)
         ms = C.c_double(0.0)
-        check(lib.hm_sp_search(self.h, net.handle, C.byref(io), C.byref(ms)))
+        rc = lib.hm_sp_search(self.h, net.handle, C.byref(io), C.byref(ms))
+        if rc and (lib.hm_sp_search_stalled(self.h) or lib.hm_sp_search_not_concurrent(self.h)):
+            # the hang guard gave the search up (or the launch was not resident at once): the same recovery as the self-play driver's —
+            # every slot back to the start of its search, then the host-driven loop (same results)
+            self.stalls = getattr(self, "stalls", 0) + 1
+            check(lib.hm_sp_begin_again(self.h))
+            self.cur = 0
+            self.run(net)
+            return ms.value
+        check(rc)
         return ms.value
 
     def search_consumers(self) -> int:

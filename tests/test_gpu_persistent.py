@@ -1,4 +1,4 @@
-"""Persistent search (hm_sp_search: k_search + rise_serve joined by the device-side queue of hm_queue.hpp) against the
+"""Single-launch search (hm_sp_search: the game and evaluator workgroups of k_rollout joined by the device-side queue of hm_queue.hpp) against the
 host-driven lockstep loop (hm_sp_collect || forward -> hm_sp_process), which the other suites pin to the oracle: per game the
 order of tree operations is the same, so root edge lists / visits / priors / Q, node counts, collision counters and whole
 self-play records must be IDENTICAL — whatever the relative timing of games and evaluator workgroups in a given run.
@@ -144,6 +144,42 @@ def test_stalled_persistent_search_is_repeated_with_the_same_records(hm, monkeyp
     assert res_b.persistent_stalls + res_b.persistent_searches == res_a.persistent_searches
     assert cnt_b == cnt_a and rec_b == rec_a
     assert (res_b.samples, res_b.total_nodes) == (res_a.samples, res_a.total_nodes)
+
+
+@pytest.mark.parametrize("per_wg", [1, 3])
+def test_search_abandoned_half_way_is_repeated_with_the_same_records(hm, monkeypatch, per_wg):
+    """Recovery from a search the hang guard gives up MID-WAY: the hook makes an evaluator workgroup raise "stalled" once
+    150 rows of every third search have been published — games are left in any phase, trees / transposition tables / game records
+    half-built, rows published to a queue nobody serves any more.  hm_sp_begin_again + the lockstep loop must produce the records of
+    an undisturbed run, for one game per search workgroup (search_role, node pool in LDS) and for several (search_role_mg)."""
+    net = _net()
+    monkeypatch.setenv("HM_SEARCH_GAMES_PER_WG", str(per_wg))
+    kw = dict(games=16, nodes=100, seed=9, concurrent_games=16, max_macro_plies=50)
+    res_a, rec_a, cnt_a = _selfplay(hm, net, **kw)
+    assert res_a.persistent_searches > 6 and res_a.persistent_stalls == 0
+    monkeypatch.setenv("HM_SEARCH_ABORT_EVERY", "3")
+    monkeypatch.setenv("HM_SEARCH_ABORT_AFTER", "150")
+    res_b, rec_b, cnt_b = _selfplay(hm, net, **kw)
+    monkeypatch.delenv("HM_SEARCH_ABORT_EVERY")
+    assert res_b.persistent_stalls > 0 and res_b.persistent_searches > 0
+    assert cnt_b == cnt_a and rec_b == rec_a
+    assert (res_b.samples, res_b.total_nodes) == (res_a.samples, res_a.total_nodes)
+    # the direct call recovers the same way (SearchEngine.search_persistent)
+    G = 12
+    roots = O.random_positions(77, G * 5, 100)[::5][:G].copy()
+    eng = hm.SearchEngine(G, 421)
+    eng.set_games(roots)
+    eng.begin_search(300, None, 0.0, 0.0)
+    eng.run(net)
+    want = eng.root_stats()
+    monkeypatch.setenv("HM_SEARCH_ABORT_EVERY", "1")
+    eng.set_games(roots)
+    eng.begin_search(300, None, 0.0, 0.0)
+    eng.search_persistent(net)
+    monkeypatch.delenv("HM_SEARCH_ABORT_EVERY")
+    assert getattr(eng, "stalls", 0) == 1
+    _stats_equal(want, eng.root_stats(), G)
+    eng.close()
 
 
 @pytest.mark.parametrize("per_wg", [2, 4])

@@ -40,6 +40,9 @@ def short_name(k):
     m = re.match(r"_ZN3hmn19rise_forward_narrowILi(\d+)ELb(\d)EE", k.strip())     # rocprofv3 leaves this template mangled
     if m:
         return f"rise_forward_narrow<{m.group(1)},{'true' if m.group(2) == '1' else 'false'}>"
+    m = re.match(r"_ZN3hms9k_rolloutILi(\d+)ELi(\d+)ELb(\d)EE", k.strip())
+    if m:
+        return f"k_rollout<{m.group(1)},{m.group(2)},{'true' if m.group(3) == '1' else 'false'}>"
     k = re.sub(r"\(.*\)$", "", k.strip())
     k = re.sub(r"^void ", "", k)
     return k.replace("hms::", "").replace("hmn::", "").replace("hmd::", "")
@@ -51,7 +54,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
     ap.add_argument("--algo-log", default=None, help="stdout of the profiled command (tools/run_selfplay.py prints ALGO_BYTES_PER_LAUNCH {...}): algorithmic bytes per launch of the same phase")
-    ap.add_argument("--kernels", default="k_collect,k_process,k_begin,rise_forward,encode_planes_kernel,perft", help="substrings to keep")
+    ap.add_argument("--kernels", default="k_rollout,k_collect,k_process,k_begin,rise_forward,encode_planes_kernel,perft", help="substrings to keep")
     a = ap.parse_args()
     keep = [s for s in a.kernels.split(",") if s]
     acc = {}

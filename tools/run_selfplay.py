@@ -48,6 +48,12 @@ if not res.persistent_searches:
     algo = {"k_collect": (res.nodes_visited * (64 + 104) + res.edges_scanned * 40 + res.leaf_move_words * 4) / it_ + rows_ * 9472,
             "rise_forward": rows_ * (9472 + 2 * 9344 + 10) + 2.0e6,          # planes in, both policy planes + value heads out, the packed weights once
             "launches": it_, "rows_per_launch": rows_}
+else:
+    # single-launch search (k_rollout): bench.py's formula — 40 B per scanned / updated edge, 2 x 232 B per created node's position record,
+    # 9472 B of planes + 12 B per legal move (list out, sorted moves / priors back) per network leaf — per launch (= per searched ply)
+    n_ = max(res.persistent_searches, 1)
+    algo = {"k_rollout": (res.edges_scanned * 40 + res.nodes_visited * 40 + res.total_nodes * 2 * 232 + res.eval_rows * 9472 + res.leaf_move_words * 12) / n_,
+            "launches": n_, "rows_per_launch": res.eval_rows / n_}
 print("ALGO_BYTES_PER_LAUNCH " + json.dumps(algo))
 print(json.dumps(dict(games=res.games, samples=res.samples, searched=res.searched_positions, nodes=res.total_nodes,
                       eval_rows=res.eval_rows, eval_batches=res.eval_batches, iters=res.search_iterations, raw=res.raw_plies,
