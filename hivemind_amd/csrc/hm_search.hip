@@ -1182,16 +1182,33 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
     return 0;
 }
 
-// Evaluator workgroups a single-launch search of this engine runs beside its game workgroups: a workgroup of either role takes a
-// whole CU (LDS), so all of them are resident at once — which the queue protocol relies on only for speed, every spin being
-// bounded — when their number does not exceed the CU count.
-int hm_sp_search_consumers(const hm_sp* sp) {
-    if (!sp || sp->numCUs <= 0) return 0;
+// Evaluator workgroups a single-launch search of this engine runs beside its game workgroups (0: not available): a workgroup of
+// either role takes a whole CU, so all of them are resident at once — which the queue protocol relies on only for speed, every spin
+// being bounded — when their number does not exceed the CU count.
+// Geometry of a single-launch search of this engine: games per search workgroup, search workgroups, evaluator workgroups.
+// One game per workgroup (node pool in LDS) while the games leave the evaluator three quarters of the device; more game slots than
+// that (e.g. 256 concurrent games) share search workgroups (search_role_mg) so that the launch stays resident at once — up to
+// MG_MAX games per workgroup.  A slow evaluator (the 384-channel network) starts from 3 games per workgroup (measured, see below).
+static bool rollout_plan(const hm_sp* sp, bool slowNet, int* perWgOut, int* searchWgsOut, int* consumersOut) {
+    if (!sp || sp->numCUs <= 0) return false;
+    int perWg = slowNet ? 3 : 1;                               // measured at configs[3]: 518 / 546 / 550 / 529 positions/s with 1 / 2 / 3 / 4 games per workgroup
+    if (const char* e = std::getenv("HM_SEARCH_GAMES_PER_WG")) perWg = std::max(1, std::min(MG_MAX, std::atoi(e)));
+    else while ((sp->nGames + perWg - 1) / perWg > sp->numCUs / 4 && perWg < MG_MAX) ++perWg;
+    const int searchWgs = perWg > 1 ? (sp->nGames + perWg - 1) / perWg : sp->nGames;
     const int slots = sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames;
     const int act = std::min(slots, sp->nGames);
-    // no more of them than rows can be in flight (two batches of BATCH rows per searching game, and a few to spare)
-    const int n = std::min(sp->numCUs - act, 2 * BATCH * act + 8);
-    return (sp->numCUs - sp->nGames) >= 8 && n >= 8 ? n : 0;
+    // every CU the games leave, but no more evaluator workgroups than rows can be in flight (two batches of BATCH rows per searching game, and a few to spare)
+    const int resident = perWg > 1 ? searchWgs : act;          // (with one game per workgroup the workgroups of idle slots leave at once)
+    const int consumers = std::min(sp->numCUs - resident, 2 * BATCH * act + 8);
+    if (sp->numCUs - searchWgs < 8 || consumers < 8) return false;
+    if (perWgOut) *perWgOut = perWg;
+    if (searchWgsOut) *searchWgsOut = searchWgs;
+    if (consumersOut) *consumersOut = consumers;
+    return true;
+}
+int hm_sp_search_consumers(const hm_sp* sp) {
+    int consumers = 0;
+    return rollout_plan(sp, false, nullptr, nullptr, &consumers) ? consumers : 0;
 }
 
 // hm_rollout.hip, one entry per search role (0: node pool in LDS, 1: tree walked in place, 2: several games per search workgroup):
@@ -1210,18 +1227,9 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
         || !io->value_2 || !io->pi_a_2 || !io->pi_b_2 || !io->wdl_2 || !io->moves_left_2) return hm_fail(HM_ERR_INVALID, "hm_sp_search needs both plane buffers and both sets of heads");
     hm_net_serve_info ni;
     if (!hm_net_can_serve(net) || hm_net_serve_info_get(net, &ni)) return hm_fail(HM_ERR_INVALID, "this network cannot be the evaluator of the single-launch search");
-    int consumers = hm_sp_search_consumers(sp);
-    if (consumers <= 0) return hm_fail(HM_ERR_INVALID, "too many game slots for a single-launch search on this device (use the lockstep calls)");
-    // A slow evaluator (the 384-channel deployed network: 0.66 ms per position against ~0.11 ms of tree work per batch) is the limit of
-    // the whole search: one search workgroup then serves several games in turn (search_role_mg) and the CUs it frees go to the evaluator.
-    // HM_SEARCH_GAMES_PER_WG=k overrides (1 = one workgroup per game).
-    int perWg = hm_net_serve_is_slow(net) ? 3 : 1;             // measured at configs[3]: 518 / 546 / 550 / 529 positions/s with 1 / 2 / 3 / 4 games per workgroup
-    if (const char* e = std::getenv("HM_SEARCH_GAMES_PER_WG")) perWg = std::max(1, std::min(MG_MAX, std::atoi(e)));
-    const int searchWgs = perWg > 1 ? (sp->nGames + perWg - 1) / perWg : sp->nGames;
-    if (perWg > 1) {
-        const int act = std::min(sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames, sp->nGames);
-        consumers = std::max(8, std::min(sp->numCUs - searchWgs, 2 * BATCH * act + 8));
-    }
+    int perWg = 1, searchWgs = 0, consumers = 0;
+    if (!rollout_plan(sp, hm_net_serve_is_slow(net) != 0, &perWg, &searchWgs, &consumers))
+        return hm_fail(HM_ERR_INVALID, "too many game slots for a single-launch search on this device (use the lockstep calls)");
     const int mode = perWg > 1 ? 2 : (sp->searchLdsNodes ? 0 : 1);
     const void* kern = mode == 0 ? hm_rollout_kernel_mode0(ni.C / 32, ni.k5) : mode == 1 ? hm_rollout_kernel_mode1(ni.C / 32, ni.k5) : hm_rollout_kernel_mode2(ni.C / 32, ni.k5);
     if (!kern) return hm_fail(HM_ERR_INVALID, "no single-launch search kernel for this trunk width");

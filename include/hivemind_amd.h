@@ -226,25 +226,27 @@ uint64_t* hm_sp_leg_clock_net(hm_sp* sp);
  * collected batch to evaluator workgroups (Engine::enqueueInferenceHalf / synchronizeInferenceHalf, nn/engine.h:43-81, one
  * position per workgroup) the moment it is written.  Per game the order of tree operations — hence every visit count — is the
  * lockstep one; a game no longer waits for the slowest game of an iteration.  io: both plane buffers and both sets of heads
- * (hm_eval_io of the native mode).  Synchronous (synchronises the device first); the two kernels run on two streams of the
- * engine that own their hardware queues.  A profiler that serialises kernels (rocprofv3 --pmc) makes it give up after a few
- * seconds with HM_ERR_STATE: profile counters on the lockstep calls (HM_SELFPLAY_LOCKSTEP=1 for the self-play driver).  Needs hm_sp_search_consumers(sp) > 0 (game slots plus
- * at least 8 evaluator workgroups within the device's CU count) and a network with a persistent evaluator kernel (trunks of
- * 64 / 128 / 384 channels); otherwise HM_ERR_INVALID — use the lockstep calls. */
+ * (hm_eval_io of the native mode).  Synchronous (synchronises the device first).  ONE kernel launch (k_rollout, hm_rollout.hip):
+ * the first workgroups of the grid are the games, the others the evaluator, joined by a device-side queue (hm_queue.hpp) — so it
+ * also runs under profilers that serialise kernels (rocprofv3 --pmc).  Needs hm_sp_search_consumers(sp) > 0 (game slots plus at
+ * least 8 evaluator workgroups within the device's CU count) and a network whose trunk has 64 / 128 / 384 channels; otherwise
+ * HM_ERR_INVALID — use the lockstep calls.  A search the hang guard gives up (hm_sp_search_stalled) prints its give-up record on
+ * stderr and returns HM_ERR_STATE. */
 struct hm_net;
 struct hm_eval_io;
 int hm_sp_search(hm_sp* sp, const struct hm_net* net, const struct hm_eval_io* io,
-                 double* search_kernel_ms /* optional: duration of the k_search launch, HIP events on its stream */);
-/* 1 when the last hm_sp_search gave up because its two kernels were not running together (a profiler that serialises kernels);
- * hm_sp_begin_again then restores the state hm_sp_begin_search had left (same targets, seeds, mask and noise; tree reuse off)
- * so that the lockstep calls can run the search instead. */
+                 double* search_kernel_ms /* optional: duration of the k_rollout launch, HIP events on its stream */);
+/* 1 when the last hm_sp_search gave up because no workgroup of the other role came in within 3 s (the grid was not resident at once:
+ * something else held the device's CUs); hm_sp_begin_again then restores the state hm_sp_begin_search had left (same targets,
+ * seeds, mask and noise; refused with HM_ERR_STATE while a slot keeps its tree between searches) so that the lockstep calls can
+ * run the search instead. */
 int hm_sp_search_not_concurrent(const hm_sp* sp);
-/* 1 when the last hm_sp_search was given up because its evaluator workgroups had had no row for 30 ms while games were still
- * searching (observed on MI355X about once in 800 searches with the deployed network; see hm_queue.hpp).  hm_sp_begin_again puts
- * every slot back to the start of that search; running it again — persistent or lockstep — gives the same result. */
+/* 1 when the last hm_sp_search was given up by its hang guard: neither the queue tail nor any game's phase had moved for 50 ms
+ * while games were still searching (hm_queue.hpp: IDLE_LIMIT_TICKS).  hm_sp_begin_again puts every slot back to the start of
+ * that search; running it again — single-launch or lockstep — gives the same result. */
 int hm_sp_search_stalled(const hm_sp* sp);
-/* 1 when the persistent search keeps this engine's node pool in LDS for a whole search (the pool fits beside k_search's static LDS:
- * node budgets up to about 1 500 nodes), 0 when it walks the tree in place. */
+/* 1 when the single-launch search keeps this engine's node pool in LDS for a whole search (the pool fits behind the search role's
+ * fixed LDS), 0 when it walks the tree in place. */
 int hm_sp_search_lds_tree(const hm_sp* sp);
 int hm_sp_begin_again(hm_sp* sp);
 /* Evaluator workgroups a persistent search of this engine runs (0: not available for this many game slots on this device). */
@@ -442,7 +444,7 @@ typedef struct hm_selfplay_result {
     double   search_seconds, prologue_seconds, raw_seconds;
     uint64_t chunks_flushed;             /* chunks handed to the sink / written to the output directory */
     uint64_t leaf_move_words;            /* 4-byte move-list entries the traversal wrote for its network leaves (roofline accounting) */
-    /* persistent searches (hm_sp_search): launches of k_search, their total duration (HIP events on the launch stream) and the
+    /* single-launch searches (hm_sp_search): launches of k_rollout, their total duration (HIP events on the launch stream) and the
      * time the games waited for evaluations; collect_ms / process_ms are then sums over game-iterations (search_iterations counts
      * game-iterations), eval_ms the evaluator workgroups' time over eval_rows positions */
     uint64_t persistent_searches;
