@@ -11,7 +11,13 @@
 #define HM_NPF_PROJ 0      // the same for the 1x1 projection of the 384-channel variant (its accumulators are live across the chunks)
 #endif
 #ifndef HM_NPF_WIDE4
-#define HM_NPF_WIDE4 12           // the same for the 4-wave form (narrow_position4: 512 registers per lane, two accumulators per fragment)
+#define HM_NPF_WIDE4 24           // the same for the 4-wave form (narrow_position4: 512 registers per lane, two accumulators per fragment)
+#endif
+#ifndef HM_NPF_PROJ4
+#define HM_NPF_PROJ4 0            // 4-wave form, 384-channel variant: 20 = the projection tiles of a full chunk (320 expanded channels, 20 k-steps) as one fragment stream (project_stream2) — measured: 207 spilled VGPRs, not used
+#endif
+#ifndef HM_NET_PREFETCH
+#define HM_NET_PREFETCH 1         // 4-wave form, narrow trunks (C <= 128): the expand GEMM's first weight fragments are requested one phase ahead (FragQ): -1 k cycles per block
 #endif
 #ifndef HM_NPF_WIDE
 #define HM_NPF_WIDE 10            // weight-fragment requests a wave keeps in flight in the 384-channel variant (build parameter for measurements)
@@ -398,6 +404,103 @@ __device__ __forceinline__ void gemm_conv3_2(floatx16& acc0, floatx16& acc1, con
             acc1 = WA ? mfma(h8(f), h8(x1), acc1) : mfma(h8(x1), h8(f), acc1);
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// A weight-fragment queue requested AHEAD of the phase that multiplies it (4-wave form: a lane has 512 registers, so a queue can stay
+// live across a barrier, a depthwise phase or an epilogue — the L2 round trip of a GEMM's first fragments then overlaps that work
+// instead of opening the phase).  fragq_fill requests k-steps 0 .. Q-1 of `tile` (clamped to the last one, as gemm_tile2 does).
+template <int Q>
+struct FragQ { frag4 q[Q]; };
+template <int Q>
+__device__ __forceinline__ void fragq_fill(FragQ<Q>& f, const h16* w, int ntiles, int tile, int ksteps, int lane) {
+    const frag4* wp = reinterpret_cast<const frag4*>(w) + (size_t)tile * 64 + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const int last = ksteps - 1;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) f.q[j] = wp[(size_t)(j < last ? j : last) * ws];
+}
+// gemm_tile2 continuing from a queue fragq_fill has requested for the same (w, ntiles, tile, ksteps)
+template <bool WA, int Q>
+__device__ __forceinline__ void gemm_tile2_q(FragQ<Q>& f, floatx16& acc0, floatx16& acc1, const h16* xrow0, const h16* xrow1, int ksteps, const h16* w, int ntiles, int tile, int lane) {
+    const frag4* wp = reinterpret_cast<const frag4*>(w) + (size_t)tile * 64 + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const int last = ksteps - 1;
+    int base = 0;
+    for (; base + Q < ksteps; base += Q) {
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            const frag4 x0 = lds_frag(xrow0 + (base + j) * 16);
+            const frag4 x1 = lds_frag(xrow1 + (base + j) * 16);
+            const frag4 fr = f.q[j];
+            const int nxt = base + Q + j;
+            f.q[j] = wp[(size_t)(nxt < last ? nxt : last) * ws];
+            acc0 = WA ? mfma(h8(fr), h8(x0), acc0) : mfma(h8(x0), h8(fr), acc0);
+            acc1 = WA ? mfma(h8(fr), h8(x1), acc1) : mfma(h8(x1), h8(fr), acc1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        if (base + j < ksteps) {
+            const frag4 x0 = lds_frag(xrow0 + (base + j) * 16);
+            const frag4 x1 = lds_frag(xrow1 + (base + j) * 16);
+            acc0 = WA ? mfma(h8(f.q[j]), h8(x0), acc0) : mfma(h8(x0), h8(f.q[j]), acc0);
+            acc1 = WA ? mfma(h8(f.q[j]), h8(x1), acc1) : mfma(h8(x1), h8(f.q[j]), acc1);
+        }
+    }
+}
+// expand_stream2 continuing from a queue fragq_fill has requested for its first tile (ksteps == Q)
+template <int Q, typename Epi>
+__device__ __forceinline__ void expand_stream2_q(FragQ<Q>& f, const h16* xrow0, const h16* xrow1, int ksteps, const h16* w, int ntiles, int tile0, int tstride, int ntile, int lane, Epi&& epi) {
+    const frag4* base = reinterpret_cast<const frag4*>(w) + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const frag4* wp = base + (size_t)tile0 * 64;
+    for (int i = 0; i < ntile; ++i) {
+        const frag4* wn = base + (size_t)(tile0 + (i + 1 < ntile ? i + 1 : i) * tstride) * 64;
+        floatx16 acc0 = zero16(), acc1 = zero16();
+        for (int b = 0; b < ksteps; b += Q) {
+            const frag4* nx = b + Q < ksteps ? wp + (size_t)(b + Q) * ws : wn;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const frag4 x0 = lds_frag(xrow0 + (b + j) * 16);
+                const frag4 x1 = lds_frag(xrow1 + (b + j) * 16);
+                const frag4 fr = f.q[j];
+                f.q[j] = nx[(size_t)j * ws];
+                acc0 = mfma(h8(fr), h8(x0), acc0);
+                acc1 = mfma(h8(fr), h8(x1), acc1);
+            }
+        }
+        epi(i, acc0, acc1);
+        wp = wn;
+    }
+}
+
+// A wave's T projection tiles (channel tiles tile0, tile0 + tstride, ...; both square halves each; accumulators carried by the caller) as
+// ONE weight-fragment stream with K = Q k-steps per tile: every queue slot is refilled with the NEXT tile's fragment of the same k-step
+// right after its use, so only the first tile pays the weight-fetch latency (the 384-channel network's full chunks: K = Q = 20).
+// Tiles i >= ntile are skipped; the last tile re-requests its own fragments instead of branching.
+template <int Q, int T>
+__device__ __forceinline__ void project_stream2(floatx16 (&acc)[T][2], const h16* xrow0, const h16* xrow1, const h16* w, int ntiles, int tile0, int tstride, int ntile, int lane) {
+    const frag4* base = reinterpret_cast<const frag4*>(w) + lane;
+    const size_t ws = (size_t)ntiles * 64;
+    const frag4* wp = base + (size_t)tile0 * 64;
+    frag4 q[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) q[j] = wp[(size_t)j * ws];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        if (i < ntile) {
+            const frag4* wn = base + (size_t)(tile0 + (i + 1 < ntile ? i + 1 : i) * tstride) * 64;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const frag4 x0 = lds_frag(xrow0 + j * 16);
+                const frag4 x1 = lds_frag(xrow1 + j * 16);
+                const frag4 fr = q[j];
+                q[j] = wn[(size_t)j * ws];
+                acc[i][0] = mfma(h8(x0), h8(fr), acc[i][0]);
+                acc[i][1] = mfma(h8(x1), h8(fr), acc[i][1]);
+            }
+        }
     }
 }
 
@@ -789,6 +892,7 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
     h16* Pol = polOff + 160 * 64 + PRIOR_SCRATCH_HALFS <= uHalfs ? U + polOff : Xs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = 8 * (lane >> 5);
+    constexpr bool PF = HM_NET_PREFETCH != 0 && CTILES <= 4;           // (the 384-channel variant spills with the extra queue: 1.07 -> 1.24 ms per position)
     const int sq0 = lane & 31;                                          // the square this lane feeds as an A-row / B-column in half 0 (half 1: + 32)
 
     {
@@ -817,6 +921,10 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                 }
             }
         }
+        // The expand GEMM's first weight fragments (this wave's first channel tile of the block's first chunk) are requested one phase
+        // ahead: here for block 0, after each projection for the chunk / block that follows (see FragQ).
+        FragQ<NPF> eq;
+        if (PF && nd.nblocks > 0) fragq_fill<NPF>(eq, wh + nd.blk[0].w1, nd.blk[0].cop >> 5, wave, C >> 4, lane);
         __syncthreads();
         HM_STAMP();
         // ---- mobile bottleneck blocks: three phases each over (a chunk of) the `cop` expanded channels
@@ -831,8 +939,12 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                 // work item = (quarter p of the squares / input channels, channel c): 4*C items over the workgroup
                 for (int it = tid; it < 4 * C; it += 256) {
                     const int c = it % C, p = it / C;
+                    h16 xv[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xv[j] = Xs[(16 * p + j) * ldx + c];       // sixteen LDS reads in flight, then the adds in the same order
                     float sacc = 0.0f;
-                    for (int sq = 16 * p; sq < 16 * p + 16; ++sq) sacc += (float)Xs[sq * ldx + c];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sacc += (float)xv[j];
                     part[p * C + c] = sacc;
                 }
                 __syncthreads();
@@ -845,22 +957,32 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                 {
                     const h16* we = wh + bd.ecaw;                       // [ci][co]
                     constexpr int CG = C >> 3, ROWS = C >> 5;
-                    for (int it = tid; it < 32 * CG; it += 256) {
-                        const int cg = it % CG, p = it / CG;
-                        float s[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        const h16* wrow = we + (size_t)(p * ROWS) * C + 8 * cg;
-                        half8 w8[ROWS];
+                    // (two work items per thread and round — a thread's 2 * ROWS row loads are requested together: with four waves a thread has
+                    // two or more items, and one L2 round trip serves both)
+                    for (int it0 = tid; it0 < 32 * CG; it0 += (CTILES <= 4 ? 512 : 256)) {
+                        const int itB = it0 + 256;
+                        const bool hasB = CTILES <= 4 && itB < 32 * CG;       // (the 384-channel variant: one item per round, its 12 row loads already fill the queue)
+                        const int cgA = it0 % CG, pA = it0 / CG, cgB = hasB ? itB % CG : cgA, pB = hasB ? itB / CG : pA;
+                        const h16* wrowA = we + (size_t)(pA * ROWS) * C + 8 * cgA;
+                        const h16* wrowB = we + (size_t)(pB * ROWS) * C + 8 * cgB;
+                        half8 wA[ROWS], wB[ROWS];
 #pragma unroll
-                        for (int u = 0; u < ROWS; ++u) w8[u] = *reinterpret_cast<const half8*>(wrow + (size_t)u * C);
+                        for (int u = 0; u < ROWS; ++u) { wA[u] = *reinterpret_cast<const half8*>(wrowA + (size_t)u * C); wB[u] = *reinterpret_cast<const half8*>(wrowB + (size_t)u * C); }
+                        float sA[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, sB[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                         for (int u = 0; u < ROWS; ++u) {
-                            const float m = Mv[p * ROWS + u];
+                            const float mA = Mv[pA * ROWS + u], mB = Mv[pB * ROWS + u];
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) s[k] += (float)w8[u][k] * m;
+                            for (int k = 0; k < 8; ++k) { sA[k] += (float)wA[u][k] * mA; sB[k] += (float)wB[u][k] * mB; }
                         }
-                        float* dst = part32 + p * C + 8 * cg;
+                        float* dA = part32 + pA * C + 8 * cgA;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) dst[k] = s[k];
+                        for (int k = 0; k < 8; ++k) dA[k] = sA[k];
+                        if (hasB) {
+                            float* dB = part32 + pB * C + 8 * cgB;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) dB[k] = sB[k];
+                        }
                     }
                 }
                 __syncthreads();
@@ -871,6 +993,7 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                     Mv[c] = fminf(fmaxf(sg * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
                 }
                 __syncthreads();
+#pragma unroll 4
                 for (int i = tid; i < 32 * C; i += 256) {               // two adjacent channels per item
                     const int sq = i / (C >> 1), cc = 2 * (i - sq * (C >> 1));
                     half2v* px = reinterpret_cast<half2v*>(Xs + sq * ldx + cc);
@@ -910,38 +1033,61 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                     };
                     if constexpr ((C >> 4) == NPF) {                    // narrow trunks: K = one queue, a wave's tiles as one fragment stream
                         const int ntile = ctl > wave ? (ctl - wave + 3) >> 2 : 0;
-                        if (ntile > 0)
+                        if (ntile > 0 && !PF)
                             expand_stream2<NPF>(brow0, brow1, C >> 4, wh + bd.w1, copTiles, ct0 + wave, 4, ntile, lane,
                                                 [&](int i, const floatx16& e0, const floatx16& e1) { store(wave + 4 * i, e0, e1); });
+                        else if (ntile > 0)
+                            expand_stream2_q<NPF>(eq, brow0, brow1, C >> 4, wh + bd.w1, copTiles, ct0 + wave, 4, ntile, lane,
+                                                  [&](int i, const floatx16& e0, const floatx16& e1) { store(wave + 4 * i, e0, e1); });
                     } else {
                         for (int ct = wave; ct < ctl; ct += 4) {
                             floatx16 e0 = zero16(), e1 = zero16();
-                            gemm_tile2<true, NPF>(e0, e1, brow0, brow1, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+                            if (PF && ct == wave) gemm_tile2_q<true, NPF>(eq, e0, e1, brow0, brow1, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
+                            else gemm_tile2<true, NPF>(e0, e1, brow0, brow1, C >> 4, wh + bd.w1, copTiles, ct0 + ct, lane);
                             store(ct, e0, e1);
                         }
                     }
                 }
                 __syncthreads();
                 HM_STAMP();   // expand done
-                // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows).  (Requesting the projection's
-                // first weight fragments before it was measured: the queue held across the depthwise arithmetic spills, 0.79 -> 1.03 ms.)
+                // phase 2 — depthwise kxk (+bias, ReLU): work item = (channel, pair of board rows), two items per thread and round so that
+                // one item's LDS reads overlap the other's arithmetic (a thread has eight items and its SIMD no second wave).  (Requesting
+                // the projection's first weight fragments before this phase, possible with 512 registers per lane, was measured: no gain.)
                 const h16* w2c = wh + bd.w2 + (size_t)(ch0 >> 4) * ctiles * 512;
-                for (int item = tid; item < chunk * 4; item += 256) {
-                    const int ch = item % chunk, g = item / chunk;
-                    const h16* wd = Pdw + (size_t)ch * kk * kk;
-                    if (!K5 || kk == 3) depthwise_rows_ld<3>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
-                    else depthwise_rows_ld<5>(Y1 + ch * 66, Y2, ld2, ch, g, wd, sb2[ch]);
+                for (int item = tid; item < chunk * 4; item += (CTILES <= 4 ? 512 : 256)) {
+                    const int itB = item + 256;
+                    const bool hasB = CTILES <= 4 && itB < chunk * 4;
+                    const int chA = item % chunk, gA = item / chunk, chB = hasB ? itB % chunk : chA, gB = hasB ? itB / chunk : gA;
+                    if (!K5 || kk == 3) {
+                        depthwise_rows_ld<3>(Y1 + chA * 66, Y2, ld2, chA, gA, Pdw + (size_t)chA * 9, sb2[chA]);
+                        if (hasB) depthwise_rows_ld<3>(Y1 + chB * 66, Y2, ld2, chB, gB, Pdw + (size_t)chB * 9, sb2[chB]);
+                    } else {
+                        depthwise_rows_ld<5>(Y1 + chA * 66, Y2, ld2, chA, gA, Pdw + (size_t)chA * 25, sb2[chA]);
+                        if (hasB) depthwise_rows_ld<5>(Y1 + chB * 66, Y2, ld2, chB, gB, Pdw + (size_t)chB * 25, sb2[chB]);
+                    }
                 }
                 __syncthreads();
                 HM_STAMP();   // depthwise done
                 // phase 3 — 1x1 project, K = this chunk's channels: k-steps ch0/16 .. of W2
                 // (streaming a wave's TPW tiles through one fragment queue, as the narrow expand phase does, was measured on the
                 // 384-channel variant: 108 spilled VGPRs instead of 42; kept: one call per tile)
+                constexpr int QP = HM_NPF_PROJ4 > 0 ? HM_NPF_PROJ4 : 1;  // k-steps of a full chunk of the 384-channel network (chunk 320): its tiles as one stream
+                if (HM_NPF_PROJ4 > 0 && CTILES > 4 && (chunk >> 4) == QP) {
+                    const int ntile = ctiles > wave ? (ctiles - wave + 3) >> 2 : 0;
+                    if (ntile > 0) project_stream2<QP, TPW>(pacc, Y2 + sq0 * ld2 + kh, Y2 + (sq0 + 32) * ld2 + kh, w2c, ctiles, wave, 4, ntile, lane);
+                } else {
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const int ctile = wave + 4 * i;
-                    if (ctile < ctiles)
-                        gemm_tile2<false, NPFP>(pacc[i][0], pacc[i][1], Y2 + sq0 * ld2 + kh, Y2 + (sq0 + 32) * ld2 + kh, chunk >> 4, w2c, ctiles, ctile, lane);
+                    for (int i = 0; i < TPW; ++i) {
+                        const int ctile = wave + 4 * i;
+                        if (ctile < ctiles)
+                            gemm_tile2<false, NPFP>(pacc[i][0], pacc[i][1], Y2 + sq0 * ld2 + kh, Y2 + (sq0 + 32) * ld2 + kh, chunk >> 4, w2c, ctiles, ctile, lane);
+                    }
+                }
+                {   // the expand fragments of what comes next: this block's next chunk, or the next block's first one
+                    const bool more = ch0 + copMax < cop;
+                    if (!PF) {}
+                    else if (more) fragq_fill<NPF>(eq, wh + bd.w1, copTiles, ((ch0 + copMax) >> 5) + wave, C >> 4, lane);
+                    else if (bi + 1 < nd.nblocks) fragq_fill<NPF>(eq, wh + nd.blk[bi + 1].w1, nd.blk[bi + 1].cop >> 5, wave, C >> 4, lane);
                 }
                 // (no barrier here: the next chunk's parameter stage and expand phase touch Pf / Pdw / Y1, which this phase does
                 // not read, and its depthwise phase — the next writer of Y2 — starts behind the barrier after its expand phase)
@@ -967,17 +1113,13 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
         // ---- value head: 1x1 conv C -> cv (+bias, ReLU), NCHW flatten, linear -> (wdl x3, plys)
         {
             const int cv = nd.cv;
-            if (wave == 0) {
-                floatx16 e0 = zero16(), e1 = zero16();
-                gemm_tile2<true, NPF>(e0, e1, Xs + sq0 * ldx + kh, Xs + (sq0 + 32) * ldx + kh, C >> 4, wh + nd.v_w, 1, 0, lane);
+            if (wave < 2) {                                             // one square half per wave (two waves work instead of one with both halves)
+                const int sqh = wave * 32 + sq0;
+                const floatx16 e = gemm_tile<true, NPF>(zero16(), Xs + sqh * ldx + kh, C >> 4, wh + nd.v_w, 1, 0, lane);
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
                     const int ch = drow(rg, lane);
-                    if (ch < cv) {
-                        const float b = wf[nd.v_b + ch];
-                        Y1[ch * 66 + sq0] = (h16)fmaxf(e0[rg] + b, 0.0f);
-                        Y1[ch * 66 + 32 + sq0] = (h16)fmaxf(e1[rg] + b, 0.0f);
-                    }
+                    if (ch < cv) Y1[ch * 66 + sqh] = (h16)fmaxf(e[rg] + wf[nd.v_b + ch], 0.0f);
                 }
             }
             __syncthreads();
@@ -1048,19 +1190,29 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
         __syncthreads();
         HM_STAMP();
         {
-            // 146 output planes padded to 160 = 5 channel tiles (both square halves each) over 4 waves
-            for (int ct = wave; ct < 5; ct += 4) {
+            // 146 output planes padded to 160 = 5 channel tiles: tiles 0..3 with both square halves on waves 0..3, the two halves of tile 4
+            // as single tiles on waves 1 and 2 (five pairs over four waves would leave one wave with twice the work)
+            auto put = [&](int ch, int sq, float v) {
+                if constexpr (WT) Pol[ch * 64 + sq] = (h16)v;                                   // [160][64] staging behind Ss
+                else {
+                    if (ch < 73) piA[(size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sq] = (h16)v;
+                    else if (ch < 146) piB[(size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sq] = (h16)v;
+                }
+            };
+            {
                 floatx16 e0 = zero16(), e1 = zero16();
-                gemm_conv3_2<CTILES * 2, true>(e0, e1, Ss, sq0, ldx, 64, kh, wh + nd.pp_w, 5, ct, lane);
+                gemm_conv3_2<CTILES * 2, true>(e0, e1, Ss, sq0, ldx, 64, kh, wh + nd.pp_w, 5, wave, lane);
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
-                    const int ch = ct * 32 + drow(rg, lane);
-                    if constexpr (WT) { Pol[ch * 64 + sq0] = (h16)e0[rg]; Pol[ch * 64 + 32 + sq0] = (h16)e1[rg]; }   // [160][64] staging behind Ss
-                    else {
-                        if (ch < 73) { h16* d = piA + (size_t)sIdx * HM_POLICY_VALUES + ch * 64 + sq0; d[0] = (h16)e0[rg]; d[32] = (h16)e1[rg]; }
-                        else if (ch < 146) { h16* d = piB + (size_t)sIdx * HM_POLICY_VALUES + (ch - 73) * 64 + sq0; d[0] = (h16)e0[rg]; d[32] = (h16)e1[rg]; }
-                    }
+                    const int ch = wave * 32 + drow(rg, lane);
+                    put(ch, sq0, e0[rg]); put(ch, 32 + sq0, e1[rg]);
                 }
+            }
+            if (wave == 1 || wave == 2) {
+                const int sqh = (wave - 1) * 32 + sq0;
+                const floatx16 e = gemm_conv3<CTILES * 2, true>(zero16(), Ss, sqh, ldx, 64, kh, wh + nd.pp_w, 5, 4, lane);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) put(4 * 32 + drow(rg, lane), sqh, e[rg]);
             }
         }
         __syncthreads();
