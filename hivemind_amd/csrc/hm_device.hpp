@@ -66,19 +66,21 @@ __device__ __forceinline__ void stage_table(T* lds, const T* g) {
 // The same with 16 bytes per lane and a thread's four requests in flight before the first is stored: the 12.5 KB rules table is
 // one round trip for a 256-thread block instead of six (the lockstep kernels stage it at the top of every launch).  Costs 16
 // VGPRs, which the occupancy-bound kernels (perft: 2.75 -> 4.2 s with this form) cannot spare: they keep the plain copy.
+// nthreads: the threads that take part (default: the whole block; k_rollout's search role runs on the first 256 threads of a block
+// that may have 512)
 template <typename T>
-__device__ __forceinline__ void stage_table_wide(T* lds, const T* g) {
+__device__ __forceinline__ void stage_table_wide(T* lds, const T* g, unsigned nthreads = blockDim.x) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     static_assert(sizeof(T) % 16 == 0 && alignof(T) >= 16, "16-byte aligned table");
     constexpr unsigned N16 = sizeof(T) / 16;
     const u32x4* src = reinterpret_cast<const u32x4*>(g);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
-    for (unsigned i0 = threadIdx.x; i0 < N16; i0 += 4 * blockDim.x) {
+    for (unsigned i0 = threadIdx.x; i0 < N16; i0 += 4 * nthreads) {
         u32x4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * blockDim.x; if (i < N16) v[u] = src[i]; }
+        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * nthreads; if (i < N16) v[u] = src[i]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * blockDim.x; if (i < N16) dst[i] = v[u]; }
+        for (int u = 0; u < 4; ++u) { const unsigned i = i0 + u * nthreads; if (i < N16) dst[i] = v[u]; }
     }
 }
 

@@ -1054,16 +1054,19 @@ __device__ __forceinline__ void narrow_position4(const NetDesc& nd, const h16* _
                 // one item's LDS reads overlap the other's arithmetic (a thread has eight items and its SIMD no second wave).  (Requesting
                 // the projection's first weight fragments before this phase, possible with 512 registers per lane, was measured: no gain.)
                 const h16* w2c = wh + bd.w2 + (size_t)(ch0 >> 4) * ctiles * 512;
-                for (int item = tid; item < chunk * 4; item += (CTILES <= 4 ? 512 : 256)) {
-                    const int itB = item + 256;
-                    const bool hasB = CTILES <= 4 && itB < chunk * 4;
-                    const int chA = item % chunk, gA = item / chunk, chB = hasB ? itB % chunk : chA, gB = hasB ? itB / chunk : gA;
-                    if (!K5 || kk == 3) {
+                if (!K5 || kk == 3) {
+                    // two 3x3 items per thread and round: one item's LDS reads overlap the other's arithmetic
+                    for (int item = tid; item < chunk * 4; item += 512) {
+                        const int itB = item + 256;
+                        const bool hasB = itB < chunk * 4;
+                        const int chA = item % chunk, gA = item / chunk, chB = hasB ? itB % chunk : chA, gB = hasB ? itB / chunk : gA;
                         depthwise_rows_ld<3>(Y1 + chA * 66, Y2, ld2, chA, gA, Pdw + (size_t)chA * 9, sb2[chA]);
                         if (hasB) depthwise_rows_ld<3>(Y1 + chB * 66, Y2, ld2, chB, gB, Pdw + (size_t)chB * 9, sb2[chB]);
-                    } else {
-                        depthwise_rows_ld<5>(Y1 + chA * 66, Y2, ld2, chA, gA, Pdw + (size_t)chA * 25, sb2[chA]);
-                        if (hasB) depthwise_rows_ld<5>(Y1 + chB * 66, Y2, ld2, chB, gB, Pdw + (size_t)chB * 25, sb2[chB]);
+                    }
+                } else {
+                    for (int item = tid; item < chunk * 4; item += 256) {
+                        const int ch = item % chunk, g = item / chunk;
+                        depthwise_rows_ld<5>(Y1 + ch * 66, Y2, ld2, ch, g, Pdw + (size_t)ch * 25, sb2[ch]);
                     }
                 }
                 __syncthreads();

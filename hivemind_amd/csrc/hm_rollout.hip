@@ -13,11 +13,13 @@
 // games are in before the first evaluator workgroup, and an evaluator workgroup that finds no CU merely starts later (every one of
 // them ends on a poison ticket of its own).
 //
+// (The workgroup size is a template parameter: see k_rollout.)
 // Compiled once per search role: -DHM_ROLLOUT_MODE=0 (node pool in LDS), 1 (tree walked in place), 2 (several games per search
 // workgroup), each for the network variants of rollout_kernel(); diagnostic builds (-DHM_SINGLE_TU) include this file from
 // hm_search.hip instead, so that the probes of hm_prof.hpp land in the one translation unit that reads them.
 #include "hm_search_device.hpp"
 #include "hm_net_device.hpp"
+#include <cstdlib>
 
 namespace hms {
 
@@ -45,7 +47,7 @@ __device__ __forceinline__ void search_role(unsigned char* smem, const Pools& pl
     Game* const gGame = s.g;
     Node* const gNodes = s.nodes;
     for (unsigned i = threadIdx.x; i < sizeof(Game) / 4; i += COLLECT_THREADS) reinterpret_cast<u32*>(&s_game)[i] = reinterpret_cast<const u32*>(gGame)[i];
-    stage_table_wide(&s_rt, pl.rules);
+    stage_table_wide(&s_rt, pl.rules, COLLECT_THREADS);
     {
         const bool alt = gGame->pwSel != 0;
         const int* pwr = alt ? pl.pwRootAlt : pl.pwRoot;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void search_role_mg(unsigned char* smem, const Pools&
     MgSlot (&s_slot)[MG_MAX] = S_.slot;
     int& s_alive = S_.alive; int& s_moved = S_.moved; int& s_abort = S_.abort;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    stage_table_wide(&s_rt, pl.rules);
+    stage_table_wide(&s_rt, pl.rules, COLLECT_THREADS);
     {
         const int g0 = w < nGames ? w : 0;
         const bool alt = pl.games[g0].pwSel != 0;                   // (one profile per launch: the caller checks)
@@ -548,13 +550,13 @@ __device__ __forceinline__ void search_role_mg(unsigned char* smem, const Pools&
 // search workgroups fill, runs the whole network on it (narrow_position, 8 waves), then the leaf's prior pipeline on the logits still
 // in LDS (PriorEpi), signals the owning game, until the queue hands it IT_POISON.
 // =======================================================================================
-// the network body for this build's workgroup size: eight waves (narrow_position) or, with -DHM_ROLLOUT_WAVES=4, four (narrow_position4)
-template <int CTILES, bool K5, typename... A>
+// the network body for the launch's workgroup size: four waves (narrow_position4) or eight (narrow_position)
+template <int CTILES, bool K5, int WAVES, typename... A>
 __device__ __forceinline__ void position_body(A&&... args) {
-    if constexpr (ROLLOUT_THREADS == 256) hmn::narrow_position4<CTILES, K5, true, hmn::PriorEpi>(static_cast<A&&>(args)...);
+    if constexpr (WAVES == 4) hmn::narrow_position4<CTILES, K5, true, hmn::PriorEpi>(static_cast<A&&>(args)...);
     else hmn::narrow_position<CTILES, K5, true, hmn::PriorEpi>(static_cast<A&&>(args)...);
 }
-template <int CTILES, bool K5>
+template <int CTILES, bool K5, int WAVES>
 __device__ __forceinline__ void serve_role(unsigned char* smem, unsigned* s_item, const hmn::NetDesc* __restrict__ ndp, const hmn::h16* __restrict__ wh, const float* __restrict__ wf,
                                            const int copMax, const int uHalfs, const hmq::ServeArgs& a) {
     using namespace hmn;
@@ -577,7 +579,7 @@ __device__ __forceinline__ void serve_role(unsigned char* smem, unsigned* s_item
         const int g = hmq::item_game(it), buf = hmq::item_buf(it), row = hmq::item_row(it);
         const size_t r = (size_t)g * 8 + row;
         PriorEpi epi{&a, (size_t)(g * 2 + buf) * 8 + row, g, (it & hmq::IT_ROOT) != 0};
-        position_body<CTILES, K5>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
+        position_body<CTILES, K5, WAVES>(nd, wh, wf, reinterpret_cast<const h16*>(a.planes[buf]) + r * HM_PLANE_VALUES, r, copMax, uHalfs, smem,
                                                     reinterpret_cast<h16*>(a.value[buf]), reinterpret_cast<h16*>(a.piA[buf]), reinterpret_cast<h16*>(a.piB[buf]),
                                                     reinterpret_cast<h16*>(a.wdl[buf]), reinterpret_cast<h16*>(a.ml[buf]), nullptr, dbgN, epi);
         hmq::drain_stores();                                        // every wave's write-through stores of the heads have left
@@ -594,25 +596,27 @@ __device__ __forceinline__ void serve_role(unsigned char* smem, unsigned* s_item
     }
 }
 
-// ONE launch: workgroups [0, searchWgs) search, the others evaluate.  256 threads per workgroup: four waves, one per SIMD, each with
-// the whole register budget of a lane (256 VGPRs + 256 AGPRs) — what the traversal wave of the search role needs, and what lets the
-// evaluator role (narrow_position4) keep two accumulator tiles per weight fragment and a deep fragment queue.  Both roles take a
-// whole CU, so the grid is resident at once when it has no more workgroups than the device has CUs.
-template <int MODE, int CTILES, bool K5>
-__global__ __launch_bounds__(ROLLOUT_THREADS, 1) void k_rollout(Pools pl, Params prm, SearchIo io, RolloutNet rn, hmq::ServeArgs a, int nGames, int perWg, int searchWgs) {
+// ONE launch: workgroups [0, searchWgs) search, the others evaluate.  Both roles take a whole CU, so the grid is resident at once
+// when it has no more workgroups than the device has CUs.  WAVES = waves per workgroup:
+//   4 (256 threads; the narrow trunks): one wave per SIMD with the lane's whole register budget (256 VGPRs + 256 AGPRs) — what the
+//     traversal wave of the search role wants; the evaluator role is narrow_position4 (two accumulator tiles per weight fragment);
+//   8 (512 threads; the 384-channel trunk, whose searches are bound by the evaluator): the evaluator role is the faster eight-wave
+//     form (narrow_position); a search workgroup keeps its first four waves and ends the others at once — with a wave-uniform test
+//     the compiler can see as such and a real s_endpgm: a plain `return` on `threadIdx.x >= 256` is a DIVERGENT exit to the compiler,
+//     which keeps those waves running through the whole role with an empty exec mask.  The search role then has 256 registers per
+//     lane (spills to scratch: a collect phase takes 0.145 ms instead of 0.108), which does not matter where games wait for evaluations.
+template <int MODE, int CTILES, bool K5, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void k_rollout(Pools pl, Params prm, SearchIo io, RolloutNet rn, hmq::ServeArgs a, int nGames, int perWg, int searchWgs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((int)blockIdx.x < searchWgs) {
-        if constexpr (ROLLOUT_THREADS > COLLECT_THREADS) {
-            // (-DHM_ROLLOUT_WAVES=8, measured and rejected — DESIGN.md 4b: a wave-uniform test the compiler can see as such, and a real
-            // s_endpgm: a plain `return` on `threadIdx.x >= 256` is a DIVERGENT exit to the compiler, which keeps those waves running
-            // through the whole role with an empty exec mask)
+        if constexpr (64 * WAVES > COLLECT_THREADS) {
             if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= COLLECT_THREADS) __builtin_amdgcn_endpgm();
         }
         if constexpr (MODE == 2) search_role_mg(smem, pl, prm, io, nGames, perWg, (int)blockIdx.x, searchWgs);
         else search_role<MODE == 0>(smem, pl, prm, io, (int)blockIdx.x);
     } else {
-        serve_role<CTILES, K5>(smem, reinterpret_cast<unsigned*>(smem + rn.itemOff), static_cast<const hmn::NetDesc*>(rn.nd), static_cast<const hmn::h16*>(rn.wh),
-                               static_cast<const float*>(rn.wf), rn.copMax, rn.uHalfs, a);
+        serve_role<CTILES, K5, WAVES>(smem, reinterpret_cast<unsigned*>(smem + rn.itemOff), static_cast<const hmn::NetDesc*>(rn.nd), static_cast<const hmn::h16*>(rn.wh),
+                                      static_cast<const float*>(rn.wf), rn.copMax, rn.uHalfs, a);
     }
 }
 
@@ -623,15 +627,23 @@ __global__ __launch_bounds__(ROLLOUT_THREADS, 1) void k_rollout(Pools pl, Params
 #error "compile with -DHM_ROLLOUT_MODE=0|1|2 (or include from hm_search.hip with HM_SINGLE_TU, which defines the three entry points itself)"
 #endif
 namespace {
+// -> the k_rollout instantiation for a trunk of `ctiles` * 32 channels and its waves per workgroup (nullptr: none)
 template <int MODE>
-const void* rollout_kernel(int ctiles, int k5) {
+const void* rollout_kernel(int ctiles, int k5, int* waves) {
     using namespace hms;
     // (4, false) is the bench's RISEv3-small (no 5x5 block: the 5x5 depthwise code and its registers are left out); every other
-    // narrow trunk runs the K5 = true instantiation of its width, which also handles 3x3 blocks
-    if (ctiles == 4 && !k5) return reinterpret_cast<const void*>(k_rollout<MODE, 4, false>);
-    if (ctiles == 4) return reinterpret_cast<const void*>(k_rollout<MODE, 4, true>);
-    if (ctiles == 2) return reinterpret_cast<const void*>(k_rollout<MODE, 2, true>);
-    if (ctiles == 12) return reinterpret_cast<const void*>(k_rollout<MODE, 12, true>);
+    // narrow trunk runs the K5 = true instantiation of its width, which also handles 3x3 blocks.  The 384-channel trunk gets
+    // eight-wave workgroups (HM_ROLLOUT_WAVES_WIDE=4 selects the four-wave kernel for measurements).
+    *waves = 4;
+    if (ctiles == 4 && !k5) return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 4>);
+    if (ctiles == 4) return reinterpret_cast<const void*>(k_rollout<MODE, 4, true, 4>);
+    if (ctiles == 2) return reinterpret_cast<const void*>(k_rollout<MODE, 2, true, 4>);
+    if (ctiles == 12) {
+        const char* e = std::getenv("HM_ROLLOUT_WAVES_WIDE");
+        if (e && std::atoi(e) == 4) return reinterpret_cast<const void*>(k_rollout<MODE, 12, true, 4>);
+        *waves = 8;
+        return reinterpret_cast<const void*>(k_rollout<MODE, 12, true, 8>);
+    }
     return nullptr;
 }
 }  // namespace
@@ -639,10 +651,10 @@ const void* rollout_kernel(int ctiles, int k5) {
 #define HM_ROLLOUT_ENTRY(m) HM_ROLLOUT_ENTRY_(m)
 extern "C" {
 #ifdef HM_SINGLE_TU
-const void* hm_rollout_kernel_mode0(int ctiles, int k5) { return rollout_kernel<0>(ctiles, k5); }
-const void* hm_rollout_kernel_mode1(int ctiles, int k5) { return rollout_kernel<1>(ctiles, k5); }
-const void* hm_rollout_kernel_mode2(int ctiles, int k5) { return rollout_kernel<2>(ctiles, k5); }
+const void* hm_rollout_kernel_mode0(int ctiles, int k5, int* waves) { return rollout_kernel<0>(ctiles, k5, waves); }
+const void* hm_rollout_kernel_mode1(int ctiles, int k5, int* waves) { return rollout_kernel<1>(ctiles, k5, waves); }
+const void* hm_rollout_kernel_mode2(int ctiles, int k5, int* waves) { return rollout_kernel<2>(ctiles, k5, waves); }
 #else
-const void* HM_ROLLOUT_ENTRY(HM_ROLLOUT_MODE)(int ctiles, int k5) { return rollout_kernel<HM_ROLLOUT_MODE>(ctiles, k5); }
+const void* HM_ROLLOUT_ENTRY(HM_ROLLOUT_MODE)(int ctiles, int k5, int* waves) { return rollout_kernel<HM_ROLLOUT_MODE>(ctiles, k5, waves); }
 #endif
 }

@@ -1213,9 +1213,9 @@ int hm_sp_search_consumers(const hm_sp* sp) {
 
 // hm_rollout.hip, one entry per search role (0: node pool in LDS, 1: tree walked in place, 2: several games per search workgroup):
 // the k_rollout instantiation for a trunk of `ctiles` * 32 channels (k5: some block has a 5x5 depthwise), or nullptr
-const void* hm_rollout_kernel_mode0(int ctiles, int k5);
-const void* hm_rollout_kernel_mode1(int ctiles, int k5);
-const void* hm_rollout_kernel_mode2(int ctiles, int k5);
+const void* hm_rollout_kernel_mode0(int ctiles, int k5, int* waves);
+const void* hm_rollout_kernel_mode1(int ctiles, int k5, int* waves);
+const void* hm_rollout_kernel_mode2(int ctiles, int k5, int* waves);
 
 // The whole node-budget search of every slot hm_sp_begin_search left in the searching state, with the native evaluator, as ONE
 // kernel launch (hm_rollout.hip: k_rollout — game workgroups and evaluator workgroups joined by the device-side queue of
@@ -1231,7 +1231,8 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     if (!rollout_plan(sp, hm_net_serve_is_slow(net) != 0, &perWg, &searchWgs, &consumers))
         return hm_fail(HM_ERR_INVALID, "too many game slots for a single-launch search on this device (use the lockstep calls)");
     const int mode = perWg > 1 ? 2 : (sp->searchLdsNodes ? 0 : 1);
-    const void* kern = mode == 0 ? hm_rollout_kernel_mode0(ni.C / 32, ni.k5) : mode == 1 ? hm_rollout_kernel_mode1(ni.C / 32, ni.k5) : hm_rollout_kernel_mode2(ni.C / 32, ni.k5);
+    int waves = 4;                                             // waves per workgroup of this network's kernel (k_rollout: 4, or 8 for the 384-channel trunk)
+    const void* kern = mode == 0 ? hm_rollout_kernel_mode0(ni.C / 32, ni.k5, &waves) : mode == 1 ? hm_rollout_kernel_mode1(ni.C / 32, ni.k5, &waves) : hm_rollout_kernel_mode2(ni.C / 32, ni.k5, &waves);
     if (!kern) return hm_fail(HM_ERR_INVALID, "no single-launch search kernel for this trunk width");
     // dynamic LDS: the larger of the two roles' layouts (they overlay each other); the evaluator's item word sits behind its own layout
     const size_t ldsSearch = search_lds_bytes(mode) + (mode == 0 ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0);
@@ -1296,7 +1297,7 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     int nGames = sp->nGames, perWgArg = perWg, searchWgsArg = searchWgs;
     void* args[] = {&sp->pl, &sp->prm, &sio, &rn, &a, &nGames, &perWgArg, &searchWgsArg};
     (void)hipEventRecord(sp->evT0, sT);            // HIP events on the stream the kernel is launched on: its launch duration
-    const hipError_t le = hipLaunchKernel(kern, dim3((unsigned)(searchWgs + consumers)), dim3(ROLLOUT_THREADS), args, ldsBytes, sT);
+    const hipError_t le = hipLaunchKernel(kern, dim3((unsigned)(searchWgs + consumers)), dim3(64u * (unsigned)waves), args, ldsBytes, sT);
     (void)hipEventRecord(sp->evT1, sT);
     if (le != hipSuccess) { (void)hipGetLastError(); return hm_fail(HM_ERR_NO_DEVICE, std::string("k_rollout launch failed: ") + hipGetErrorString(le)); }
     HIPCHK(hipStreamSynchronize(sT));

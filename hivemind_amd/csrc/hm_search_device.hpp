@@ -1830,10 +1830,6 @@ __device__ __forceinline__ void expand_share(G& s, const RulesTab& rt, ExpLds& L
 // flag, so that `s.nodes` is known to be an LDS address in that instantiation: every node access compiles to a ds_ instruction
 // instead of a flat_ one (a flat access waits on BOTH memory counters, i.e. also for the wave's outstanding global stores — the
 // virtual-loss store of the level above).
-#ifndef HM_ROLLOUT_WAVES
-#define HM_ROLLOUT_WAVES 4                   // build parameter: 4 = both roles on four waves (the evaluator is narrow_position4); 8 = the evaluator's eight-wave form, a
-#endif                                       // search workgroup ending four of its waves at once — measured and rejected (the search role then has 256 registers per lane)
-constexpr int ROLLOUT_THREADS = 64 * HM_ROLLOUT_WAVES;   // workgroup size of k_rollout
 constexpr int ROLE_TABN = 512;
 template <bool LDS_TREE>
 struct SearchLds {
