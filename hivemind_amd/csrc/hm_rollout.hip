@@ -635,7 +635,11 @@ const void* rollout_kernel(int ctiles, int k5, int* waves) {
     // narrow trunk runs the K5 = true instantiation of its width, which also handles 3x3 blocks.  The 384-channel trunk gets
     // eight-wave workgroups (HM_ROLLOUT_WAVES_WIDE=4 selects the four-wave kernel for measurements).
     *waves = 4;
-    if (ctiles == 4 && !k5) return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 4>);
+    if (ctiles == 4 && !k5) {
+        const char* e = std::getenv("HM_ROLLOUT_WAVES_NARROW");                  // measurement switch: RISEv3-small on the eight-wave kernel
+        if (e && std::atoi(e) == 8) { *waves = 8; return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 8>); }
+        return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 4>);
+    }
     if (ctiles == 4) return reinterpret_cast<const void*>(k_rollout<MODE, 4, true, 4>);
     if (ctiles == 2) return reinterpret_cast<const void*>(k_rollout<MODE, 2, true, 4>);
     if (ctiles == 12) {
