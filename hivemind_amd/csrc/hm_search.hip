@@ -781,7 +781,8 @@ struct hm_sp {
     int searchLdsNodes = 0;                // the node pool fits in LDS behind the search role's fixed LDS (hm_search_device.hpp: SearchLds)
     int numCUs = 0;
     hipEvent_t evFork = nullptr, evJoin = nullptr, evT0 = nullptr, evT1 = nullptr;
-    hipStream_t sTree = nullptr;           // the stream k_rollout is launched on (its HIP events time the kernel)
+    hipStream_t sTree = nullptr;           // (unused since the single launch runs on the null stream)
+    bool applyPending = false;             // hm_sp_apply_deferred has run: the next hm_sp_game_state checks its error flag
     bool anyReuse = false;                 // some slot keeps its tree between searches (hm_sp_set_tree_reuse): an abandoned search cannot be repeated then
     unsigned lastQueueError = 0;           // SrvQueue::error of the last hm_sp_search (4: the two roles were not resident together, 5: stalled)
     std::vector<std::pair<const void*, size_t>> ldsSet;   // k_rollout instantiations whose dynamic-LDS limit has been raised, and to what
@@ -1248,14 +1249,14 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
             }
         if (!found) { HIPCHK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); sp->ldsSet.emplace_back(kern, ldsBytes); }
     }
-    if (!sp->sTree) {
-        HIPCHK(hipStreamCreateWithFlags(&sp->sTree, hipStreamNonBlocking));
+    if (!sp->evT0) {
         HIPCHK(hipEventCreate(&sp->evT0));
         HIPCHK(hipEventCreate(&sp->evT1));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sp->h_qinit), 64, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&sp->h_qinit), 64 + sizeof(hmq::SrvQueue) - sizeof(hmq::SrvQueue::slots), hipHostMallocDefault));
     }
-    hipStream_t sT = sp->sTree;
-    HIPCHK(hipDeviceSynchronize());                    // planes / heads / pools may have been touched on other streams
+    // The null stream: the search prologue (k_begin, the noise upload) and whatever the caller queued before run there, so the launch
+    // is ordered behind them without a device-wide synchronisation (round 3 needed two streams that owned their hardware queues).
+    hipStream_t sT = nullptr;
     const hmq::QueueLayout lay((unsigned)sp->nGames, sizeof(hmq::SrvQueue));
     hmq::SrvQueue* q = reinterpret_cast<hmq::SrvQueue*>(sp->d_queue);
     unsigned* done = reinterpret_cast<unsigned*>(sp->d_queue + lay.done);
@@ -1300,6 +1301,9 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     const hipError_t le = hipLaunchKernel(kern, dim3((unsigned)(searchWgs + consumers)), dim3(64u * (unsigned)waves), args, ldsBytes, sT);
     (void)hipEventRecord(sp->evT1, sT);
     if (le != hipSuccess) { (void)hipGetLastError(); return hm_fail(HM_ERR_NO_DEVICE, std::string("k_rollout launch failed: ") + hipGetErrorString(le)); }
+    // the queue header comes down behind the kernel into pinned memory: one synchronisation for both
+    hmq::SrvQueue* const hqp = reinterpret_cast<hmq::SrvQueue*>(reinterpret_cast<unsigned char*>(sp->h_qinit) + 64);
+    HIPCHK(hipMemcpyAsync(hqp, q, offsetof(hmq::SrvQueue, slots), hipMemcpyDeviceToHost, sT));
     HIPCHK(hipStreamSynchronize(sT));
 #ifdef HM_SEARCH_HB
     {
@@ -1311,8 +1315,7 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, sp->evT0, sp->evT1) == hipSuccess) *search_kernel_ms = ms; else { *search_kernel_ms = 0.0; (void)hipGetLastError(); }
     }
-    hmq::SrvQueue hq;                                              // header only (the slots follow it)
-    HIPCHK(hipMemcpy(&hq, q, offsetof(hmq::SrvQueue, slots), hipMemcpyDeviceToHost));
+    const hmq::SrvQueue& hq = *hqp;                                // header only (the slots follow it on the device)
     sp->lastQueueError = hq.error;
     if (!hq.error) {
         // test hook: HM_SEARCH_FAKE_STALL_EVERY=k reports every k-th COMPLETED search as stalled (HM_SEARCH_ABORT_EVERY above abandons
@@ -1469,7 +1472,7 @@ int hm_sp_active(hm_sp* sp, int* active) {
     return 0;
 }
 
-int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
+static int apply_launch(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
     if (!sp || !move_a || !move_b) return hm_fail(HM_ERR_INVALID, "null argument");
     const size_t G_ = sp->nGames;
     // mask | moveA | moveB | error flag (cleared) are adjacent in the input block: one staged upload
@@ -1482,9 +1485,20 @@ int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const u
     HIPCHK(hipMemcpy(sp->d_in + from, hs + from, sp->inBytes - from, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_apply, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_moveA, sp->d_moveB, mask ? sp->d_mask : nullptr, sp->d_applyErr);
     HIPCHK(hipGetLastError());
-    int* err = reinterpret_cast<int*>(hs);
+    return 0;
+}
+int hm_sp_apply(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
+    if (int rc = apply_launch(sp, move_a, move_b, mask)) return rc;
+    int* err = reinterpret_cast<int*>(sp->h_stage);
     HIPCHK(hipMemcpy(err, sp->d_applyErr, sizeof(int), hipMemcpyDeviceToHost));
     if (*err) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
+    return 0;
+}
+// hm_sp_apply without the round trip for its error flag: the flag is checked by the hm_sp_game_state call that follows (the self-play
+// driver's per-ply chain: apply -> game state is one synchronisation instead of two).  Internal (hm_host.hpp), not part of the C ABI.
+int hm_sp_apply_deferred(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask) {
+    if (int rc = apply_launch(sp, move_a, move_b, mask)) return rc;
+    sp->applyPending = true;
     return 0;
 }
 int hm_sp_set_side(hm_sp* sp, const uint8_t* team, const uint8_t* time_adv) {
@@ -1530,15 +1544,20 @@ int hm_sp_game_state(hm_sp* sp, hm_board* boards, int* flags, void* d_boards_out
     hipLaunchKernelGGL(k_game_state, dim3(sp->nGames), dim3(64), 0, 0, sp->pl, sp->prm, sp->d_boards, sp->d_flags);
     HIPCHK(hipGetLastError());
     if (d_boards_out) HIPCHK(hipMemcpyAsync(d_boards_out, sp->d_boards, sizeof(hm_board) * G_, hipMemcpyDeviceToDevice, nullptr));
+    const unsigned char* from = reinterpret_cast<const unsigned char*>(sp->d_boards);
+    const size_t bytes = (size_t)(reinterpret_cast<const unsigned char*>(sp->d_flags) - from) + 4 * G_;
+    int* const applyErr = reinterpret_cast<int*>(sp->h_stage + ((bytes + 15) & ~(size_t)15));     // behind the boards | flags image in the pinned stage
+    const bool checkApply = sp->applyPending;
+    sp->applyPending = false;
+    if (checkApply) HIPCHK(hipMemcpyAsync(applyErr, sp->d_applyErr, sizeof(int), hipMemcpyDeviceToHost, nullptr));   // hm_sp_apply_deferred's flag rides along
     if (boards || flags) {
         // boards | flags are adjacent at the end of the output block: one download
-        const unsigned char* from = reinterpret_cast<const unsigned char*>(sp->d_boards);
-        const size_t bytes = (size_t)(reinterpret_cast<const unsigned char*>(sp->d_flags) - from) + 4 * G_;
-        HIPCHK(hipMemcpy(sp->h_stage, from, bytes, hipMemcpyDeviceToHost));
-        if (boards) std::memcpy(boards, sp->h_stage, sizeof(hm_board) * G_);
-        if (flags) std::memcpy(flags, sp->h_stage + (reinterpret_cast<const unsigned char*>(sp->d_flags) - from), 4 * G_);
+        HIPCHK(hipMemcpyAsync(sp->h_stage, from, bytes, hipMemcpyDeviceToHost, nullptr));
     }
     HIPCHK(hipStreamSynchronize(nullptr));
+    if (boards) std::memcpy(boards, sp->h_stage, sizeof(hm_board) * G_);
+    if (flags) std::memcpy(flags, sp->h_stage + (reinterpret_cast<const unsigned char*>(sp->d_flags) - from), 4 * G_);
+    if (checkApply && *applyErr) return hm_fail(HM_ERR_OVERFLOW, "game history pool full (raise max_game_plies of hm_sp_create_ex)");
     return 0;
 }
 int hm_sp_raw_policy(hm_sp* sp, const void* d_pi_a, const void* d_pi_b, hm_move* moves, float* probs, uint8_t* caps, int* counts, uint8_t* on_turn) {

@@ -44,6 +44,7 @@
 int hm_fail(int code, const std::string& msg);
 extern "C" int hm_sp_active(hm_sp* sp, int* active);
 extern "C" int hm_sp_active_on(hm_sp* sp, int* pinned_out, hipStream_t stream);
+extern "C" int hm_sp_apply_deferred(hm_sp* sp, const hm_move* move_a, const hm_move* move_b, const uint8_t* mask);   // hm_search.hip (internal): hm_sp_apply whose error flag the next hm_sp_game_state checks
 
 namespace {
 
@@ -761,6 +762,8 @@ static int selfplay_run_impl(hm_selfplay* s) {
         if (int rc = hm_sp_root_stats(s->sp, counts.data(), mA.data(), mB.data(), visits.data(), nullptr, nullptr, rootQ.data(), info.data(), E)) return rc;
         std::fill(actA.begin(), actA.end(), 0); std::fill(actB.begin(), actB.end(), 0);
         std::vector<uint8_t> applyMask(G, 0);
+        std::vector<std::pair<uint16_t, uint64_t>> margin;
+        margin.reserve(512);
         for (int g = 0; g < G; ++g) {
             if (!mask[g]) continue;
             Slot& sl = s->slots[g];
@@ -787,20 +790,27 @@ static int selfplay_run_impl(hm_selfplay* s) {
             for (int i = 0; i < n; ++i) actual += (uint64_t)std::max(0, ev[i]);
             sm.nodes = static_cast<uint32_t>(std::min<uint64_t>(actual, 0xffffffffu));
             sm.rootQ = rootQ[g];
-            for (int b = 0; b < 2; ++b) {   // marginal_policy :400-427
-                std::map<uint16_t, uint64_t> byMove;
+            for (int b = 0; b < 2; ++b) {   // marginal_policy :400-427 (an ordered map from policy index to visits there: here the pairs sorted by index, equal indices merged)
+                margin.clear();
                 uint64_t total = 0;
                 for (int i = 0; i < n; ++i) {
                     if (ev[i] <= 0) continue;
                     const hm_move mv = b == 0 ? ea[i] : eb[i];
                     const int idx = hm_policy_index(mv, boards[g].pos[b].stm);
                     if (idx < 0) return hm_fail(HM_ERR_STATE, "Move is absent from policy map");
-                    byMove[static_cast<uint16_t>(idx)] += (uint64_t)ev[i];
+                    margin.emplace_back(static_cast<uint16_t>(idx), (uint64_t)ev[i]);
                     total += (uint64_t)ev[i];
                 }
                 if (total == 0) return hm_fail(HM_ERR_STATE, "Search returned no visited root edges");
+                std::sort(margin.begin(), margin.end(), [](const std::pair<uint16_t, uint64_t>& x, const std::pair<uint16_t, uint64_t>& y) { return x.first < y.first; });
                 auto& pol = b == 0 ? sm.policyA : sm.policyB;
-                for (const auto& kv : byMove) pol.push_back({kv.first, static_cast<float>(kv.second) / static_cast<float>(total)});
+                for (size_t i = 0; i < margin.size();) {
+                    uint64_t v = 0;
+                    size_t j = i;
+                    for (; j < margin.size() && margin[j].first == margin[i].first; ++j) v += margin[j].second;
+                    pol.push_back({margin[i].first, static_cast<float>(v) / static_cast<float>(total)});
+                    i = j;
+                }
             }
             sl.samples.push_back(std::move(sm));
             const size_t teamIdx = sl.team == HM_WHITE ? 0 : 1;
@@ -829,7 +839,7 @@ static int selfplay_run_impl(hm_selfplay* s) {
             applyMask[g] = 1;
             sl.macroPly++; sl.team ^= 1; sl.adv = !sl.adv;
         }
-        if (int rc = hm_sp_apply(s->sp, actA.data(), actB.data(), applyMask.data())) return rc;
+        if (int rc = hm_sp_apply_deferred(s->sp, actA.data(), actB.data(), applyMask.data())) return rc;
         // slots whose game just ended (resignation / no action) restart at the top of the loop
         {
             std::vector<hm_board> init(G);
