@@ -439,10 +439,15 @@ def main():
             r = sp.run()
             sp.close()
             it256 = max(r.search_iterations, 1)
-            extra["selfplay_256_concurrent_games"] = {"positions_per_s": r.samples / r.seconds, "nodes_per_s": r.total_nodes / r.seconds,
-                                                      "leg_ms_per_iteration": {"collect": r.collect_ms / it256, "net": r.eval_ms / it256,
-                                                                               "process": r.process_ms / it256},
-                                                      "net_TFLOPs": r.eval_rows / it256 * flops / (r.eval_ms / it256 * 1e-3) / 1e12}
+            single = r.persistent_searches > 0
+            extra["selfplay_256_concurrent_games"] = {
+                "positions_per_s": r.samples / r.seconds, "nodes_per_s": r.total_nodes / r.seconds,
+                "search_mode": "single launch (k_rollout; the live games share search workgroups while more than a quarter of the CUs would be games)" if single else "lockstep",
+                "single_launch_searches": r.persistent_searches, "searches_repeated_after_a_stall": r.persistent_stalls,
+                "leg_ms_per_iteration": ({"collect": r.collect_ms / it256, "wait_for_evaluator": r.wait_ms / it256, "process": r.process_ms / it256,
+                                          "evaluator_per_position": r.eval_ms / max(r.eval_rows, 1)} if single else
+                                         {"collect": r.collect_ms / it256, "net": r.eval_ms / it256, "process": r.process_ms / it256}),
+                "iteration_unit": "game-iterations" if single else "lockstep iterations"}
             pl, boards, out, _ = bench_planes(hm, dev, 100, 10, rank)
             extra["plane_encode_64k"] = pl
             enc_all = _pmc_traffic(PMC_PLANES)

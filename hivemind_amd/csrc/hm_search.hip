@@ -1192,16 +1192,16 @@ int hm_sp_process(hm_sp* sp, const void* d_value, const void* d_pi_a, const void
 // MG_MAX games per workgroup.  A slow evaluator (the 384-channel network) starts from 3 games per workgroup (measured, see below).
 static bool rollout_plan(const hm_sp* sp, bool slowNet, int* perWgOut, int* searchWgsOut, int* consumersOut) {
     if (!sp || sp->numCUs <= 0) return false;
-    int perWg = slowNet ? 3 : 1;                               // measured at configs[3]: 518 / 546 / 550 / 529 positions/s with 1 / 2 / 3 / 4 games per workgroup
-    if (const char* e = std::getenv("HM_SEARCH_GAMES_PER_WG")) perWg = std::max(1, std::min(MG_MAX, std::atoi(e)));
-    else while ((sp->nGames + perWg - 1) / perWg > sp->numCUs / 4 && perWg < MG_MAX) ++perWg;
-    const int searchWgs = perWg > 1 ? (sp->nGames + perWg - 1) / perWg : sp->nGames;
     const int slots = sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames;
-    const int act = std::min(slots, sp->nGames);
+    const int act = std::min(slots, sp->nGames);               // games that search this ply (the workgroups of the other slots leave at once)
+    int perWg = slowNet ? 3 : 1;                               // measured at configs[3]: 548 / 564 / 570 positions/s with 1 / 2 / 3 games per workgroup
+    if (const char* e = std::getenv("HM_SEARCH_GAMES_PER_WG")) perWg = std::max(1, std::min(MG_MAX, std::atoi(e)));
+    else while ((act + perWg - 1) / perWg > sp->numCUs / 4 && perWg < MG_MAX) ++perWg;       // (late in a run few games are alive: back to one per workgroup)
+    const int searchWgs = perWg > 1 ? (sp->nGames + perWg - 1) / perWg : sp->nGames;
     // every CU the games leave, but no more evaluator workgroups than rows can be in flight (two batches of BATCH rows per searching game, and a few to spare)
-    const int resident = perWg > 1 ? searchWgs : act;          // (with one game per workgroup the workgroups of idle slots leave at once)
+    const int resident = perWg > 1 ? std::min(searchWgs, act) : act;
     const int consumers = std::min(sp->numCUs - resident, 2 * BATCH * act + 8);
-    if (sp->numCUs - searchWgs < 8 || consumers < 8) return false;
+    if (consumers < 8) return false;
     if (perWgOut) *perWgOut = perWg;
     if (searchWgsOut) *searchWgsOut = searchWgs;
     if (consumersOut) *consumersOut = consumers;
