@@ -554,6 +554,10 @@ __global__ __launch_bounds__(64) void k_set_games(Pools pl, Params prm, const hm
     gm.status = ST_IDLE; gm.root = -1; gm.pending = -1; gm.overflow = 0; gm.live = 1; gm.pwSel = 0;
 }
 
+__global__ void k_set_batch(Pools pl, int n, const uint8_t* b) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) pl.games[g].batch = b ? (int)b[g] : 0;
+}
 __global__ void k_set_pw_sel(Pools pl, int n, const uint8_t* sel) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) pl.games[g].pwSel = sel[g] ? 1 : 0;
@@ -1013,6 +1017,22 @@ int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw
     }
     HIPCHK(hipMemcpy(sp->d_mask, profiles, sp->nGames, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_set_pw_sel, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, sp->d_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+// Leaves per iteration of each game slot's searches (the reference's search thread collects engine->getBatchSize() leaves,
+// searchthread.cc:258-273, 663; tournaments give each network its own, tournament.h:19-20): 1 .. 8 per slot, NULL = 8 everywhere.
+// Stays until the next call (hm_sp_set_games leaves it).  Storage — context slots, plane rows, the leaf ring — is sized for 8.
+int hm_sp_set_batch_sizes(hm_sp* sp, const uint8_t* batch) {
+    if (!sp) return hm_fail(HM_ERR_INVALID, "null argument");
+    if (batch) {
+        for (int g = 0; g < sp->nGames; ++g)
+            if (batch[g] < 1 || batch[g] > BATCH) return hm_fail(HM_ERR_INVALID, "batch sizes must be between 1 and 8");
+        HIPCHK(hipMemcpy(sp->d_mask, batch, sp->nGames, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_set_batch, dim3((sp->nGames + 63) / 64), dim3(64), 0, 0, sp->pl, sp->nGames, batch ? sp->d_mask : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;

@@ -139,6 +139,7 @@ struct Game {
     int lastRootP1;                     // 1 + root of this slot's previous search, whose tree is still in the pool (0 = none: reset_search_state)
     int reuseMode;                      // 0 = every search starts from an empty pool; 1 = reuse when the node budget still fits; 2 = and shrink the budget to what fits
     int reusedVisits;                   // visits of the recovered root, -1 = fresh root
+    int batch;                          // leaves collected per iteration (Engine::getBatchSize(), searchthread.cc:258-273, 663): 1 .. BATCH, 0 = BATCH (hm_sp_set_batch_sizes)
 };
 
 struct Params {          // device-visible configuration + pool geometry
@@ -1426,6 +1427,7 @@ __device__ __forceinline__ void collect_finish(G& s, WaveLds& L, int buf, int nc
 __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds& L, int buf, int rootTeam, bool rootAdv, int* tail = nullptr) {
     const int lane = threadIdx.x & 63;
     int nctx = 0, attempts = 0;
+    const int bsz = s.g->batch > 0 ? s.g->batch : BATCH;         // this slot's batch size (storage is sized for BATCH)
     bool posted = false;
     Desc d;
     bool running = false;        // d is a descent in progress (being repeated after a cancel, or continued after a hand-back)
@@ -1475,7 +1477,7 @@ __device__ __forceinline__ void collect_batch(G& s, const RulesTab& rt, WaveLds&
             }
         } else {
             if (!running) {
-                if (!(nctx < BATCH && attempts < BATCH * 2)) {
+                if (!(nctx < bsz && attempts < bsz * 2)) {
                     if (resolve_create(s)) break;                  // the batch stands once the last creation went the assumed way
                     continue;
                 }

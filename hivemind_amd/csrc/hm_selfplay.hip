@@ -995,7 +995,7 @@ static int tournament_run_impl(hm_tournament* t) {
     const int E = hm_sp_max_edges(s->sp);
     std::vector<hm_board> boards(G), init(G);
     std::vector<int> flags(G), counts(G), target(G), info((size_t)G * HM_SP_INFO_INTS), visits((size_t)G * E);
-    std::vector<uint8_t> mask(G), profile(G), applyMask(G);
+    std::vector<uint8_t> mask(G), profile(G), applyMask(G), batchSz(G, 8);
     std::vector<hm_move> mA((size_t)G * E), mB((size_t)G * E), actA(G), actB(G);
     std::vector<float> rootQ(G);
     std::vector<uint64_t> seeds(G);
@@ -1042,6 +1042,10 @@ static int tournament_run_impl(hm_tournament* t) {
             seeds[g] = sl.active ? tournament_seed(c.seed, (sl.gameIndex / 2) * c.max_macro_plies + sl.macroPly) : 0;
         }
         if (int rc = hm_sp_set_pw_profiles(s->sp, c.baseline_pw_coefficient, c.baseline_pw_coefficient, profile.data())) return rc;
+        if (c.contender_batch_size != 8 || c.baseline_batch_size != 8) {      // each network searches with its own batch size (tournament.h:19-20, searchthread.cc:663)
+            for (int g = 0; g < G; ++g) batchSz[g] = (uint8_t)(profile[g] ? c.baseline_batch_size : c.contender_batch_size);
+            if (int rc = hm_sp_set_batch_sizes(s->sp, batchSz.data())) return rc;
+        }
         if (s->d_netSel && hipMemcpy(s->d_netSel, profile.data(), (size_t)G, hipMemcpyHostToDevice) != hipSuccess) return hm_fail(HM_ERR_NO_DEVICE, "hipMemcpy failed");
         if (int rc = hm_sp_begin_search(s->sp, target.data(), seeds.data(), c.dirichlet_alpha, c.dirichlet_epsilon, mask.data())) return rc;
         if (int rc = run_search_lockstep(s, c.move_time_ms > 0 ? 0 : (int)c.nodes)) return rc;
@@ -1178,7 +1182,7 @@ int hm_tournament_create(const hm_tournament_config* cfg, const hm_search_config
     // what this engine does not build
     if (c.move_time_ms > 0 && !io->net) return hm_fail(HM_ERR_INVALID, "a movetime tournament is built for the native evaluator only (two networks)");
     if (c.move_time_ms > 0 && c.max_search_nodes < 0) return hm_fail(HM_ERR_INVALID, "max_search_nodes must not be negative");
-    if (c.contender_batch_size != 8 || c.baseline_batch_size != 8) return hm_fail(HM_ERR_INVALID, "only the default batch size 8 is built");
+    if (c.contender_batch_size > 8 || c.baseline_batch_size > 8) return hm_fail(HM_ERR_INVALID, "batch sizes above 8 are not built");
     if (c.concurrent_games < 1) return hm_fail(HM_ERR_INVALID, "concurrent_games must be positive");
     if ((io->net != nullptr) != (baseline_net != nullptr)) return hm_fail(HM_ERR_INVALID, "give both networks, or a callback that serves both");
     hm_selfplay_config sc;

@@ -48,6 +48,7 @@ _SIGS = {
     "hm_rules_probe": (_i, [_vp, C.c_size_t, _vp, _vp]),
     "hm_sp_classify": (_i, [_vp, _vp, _vp]),
     "hm_sp_set_pw_profiles": (_i, [_vp, C.c_float, C.c_float, _vp]),
+    "hm_sp_set_batch_sizes": (_i, [_vp, _vp]),
     "hm_sp_set_side": (_i, [_vp, _vp, _vp]),
     "hm_sp_stop": (_i, [_vp, _vp, _vp]),
     "hm_sp_profile": (_i, [_vp, _i]),
@@ -128,6 +129,11 @@ class SearchEngine:
         b = np.ascontiguousarray(move_b, dtype=np.uint32)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         check(lib.hm_sp_apply(self.h, a.ctypes.data, b.ctypes.data, _p(m)))
+
+    def set_batch_sizes(self, batch=None):
+        """Leaves per search iteration and slot (Engine::getBatchSize(), searchthread.cc:663): 1 .. 8 each, None = 8 everywhere."""
+        b = None if batch is None else np.ascontiguousarray(np.broadcast_to(np.asarray(batch, dtype=np.uint8), (self.G,)))
+        check(lib.hm_sp_set_batch_sizes(self.h, _p(b)))
 
     # ---- search -----------------------------------------------------------------------
     def begin_search(self, target_nodes, noise_seeds=None, alpha=0.0, eps=0.0, mask=None):

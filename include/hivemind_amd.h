@@ -199,6 +199,11 @@ int hm_sp_stop(hm_sp* sp, const uint8_t* mask, void* stream);
 /* Progressive-widening schedule per game slot (TournamentConfig::searchConfigFor, tools/tournament.h:34-41): profiles[g] != 0
  * makes slot g search with the alternate coefficients (root and interior); 0 = the engine's hm_search_config. */
 int hm_sp_set_pw_profiles(hm_sp* sp, float alt_pw_coefficient, float alt_root_pw_coefficient, const uint8_t* profiles);
+/* Leaves collected per search iteration, per game slot: the reference's SearchThread collects engine->getBatchSize() leaves
+ * (search/searchthread.cc:258-273, 663; Engine(deviceId, batchSize) nn/engine.h:43; tournaments give each network its own,
+ * tools/tournament.h:19-20).  batch[g] in 1 .. 8 (NULL: 8 everywhere, the reference's SearchParams::BATCH_SIZE); stays until the
+ * next call.  Larger batches are not built (context slots, plane rows and the leaf ring are sized for 8). */
+int hm_sp_set_batch_sizes(hm_sp* sp, const uint8_t* batch);
 /* (Re)start games from host boards[n_games] (Board::set, board.cc:27-49: history restarts);
  * team / time_adv of each hm_board give the side to act.  mask[g]==0 leaves game g alone. */
 int hm_sp_set_games(hm_sp* sp, const hm_board* boards, const uint8_t* mask);

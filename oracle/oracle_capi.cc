@@ -170,6 +170,7 @@ void ora_search_set_noise(void* sp, float alpha, float eps, uint64_t seed) {
     Search* s = static_cast<Search*>(sp);
     s->cfg.rootDirichletAlpha = alpha; s->cfg.rootDirichletEpsilon = eps; s->cfg.rootNoiseSeed = seed;
 }
+void ora_search_set_batch_size(void* sp, int b) { static_cast<Search*>(sp)->cfg.batchSize = b; }   // Engine::getBatchSize() (searchthread.cc:663)
 void ora_search_set_transpositions(void* sp, int on) { static_cast<Search*>(sp)->cfg.enableTranspositions = on != 0; }
 int ora_search_run(void* sp, void* board, int team, int adv, int targetNodes) {
     Search* s = static_cast<Search*>(sp);

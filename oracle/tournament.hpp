@@ -125,7 +125,7 @@ public:
     TournamentResult result;
     std::vector<TournamentGame> games;
 
-    void validate() const {   // :334-358 (the batch sizes only exist as configuration here: B = 8)
+    void validate() const {   // :334-358
         if (cfg.games == 0 || cfg.games % 2 != 0) throw std::invalid_argument("Tournament games must be a positive even number");
         if ((cfg.nodes == 0) == (cfg.moveTimeMs <= 0) || cfg.maxMacroPlies == 0)
             throw std::invalid_argument("Tournament requires exactly one positive nodes or movetime limit");
@@ -149,6 +149,7 @@ public:
             if (board.is_draw()) { g.termination = "draw"; break; }
             const bool contenderActing = team == contenderTeam;
             search.evaluator = contenderActing ? contender : baseline;
+            search.cfg.batchSize = contenderActing ? cfg.contenderBatchSize : cfg.baselineBatchSize;   // the acting network's Engine batch size (tournament.h:19-20; searchthread.cc:663 ensureBufferSize(engine->getBatchSize()))
             search.cfg.pwCoefficient = cfg.pwCoefficientFor(contenderActing);      // searchConfigFor tournament.h:34-41
             search.cfg.rootPwCoefficient = cfg.pwCoefficientFor(contenderActing);
             search.cfg.rootDirichletAlpha = cfg.dirichletAlpha;

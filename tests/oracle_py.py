@@ -177,6 +177,7 @@ lib.ora_search_free.restype, lib.ora_search_free.argtypes = None, [_vp]
 lib.ora_search_set_noise.restype, lib.ora_search_set_noise.argtypes = None, [_vp, C.c_float, C.c_float, _u64]
 lib.ora_search_tt_hits.restype, lib.ora_search_tt_hits.argtypes = _i, [_vp]
 lib.ora_search_set_transpositions.restype, lib.ora_search_set_transpositions.argtypes = None, [_vp, _i]
+lib.ora_search_set_batch_size.restype, lib.ora_search_set_batch_size.argtypes = None, [_vp, _i]
 lib.ora_search_run.restype, lib.ora_search_run.argtypes = _i, [_vp, _vp, _i, _i, _i]
 lib.ora_search_edges.restype, lib.ora_search_edges.argtypes = _i, [_vp, _vp, _vp, _vp, _vp, _vp, _i]
 lib.ora_search_root_q.restype, lib.ora_search_root_q.argtypes = C.c_float, [_vp]
@@ -213,6 +214,7 @@ class Search:
             pass
 
     def set_noise(self, alpha, eps, seed): lib.ora_search_set_noise(self.h, alpha, eps, seed)
+    def set_batch_size(self, b): lib.ora_search_set_batch_size(self.h, int(b))                # Engine::getBatchSize(): leaves per iteration (default 8)
     def set_tree_reuse(self, on=True): lib.ora_search_set_tree_reuse(self.h, int(on))      # ENABLE_TREE_REUSE between run() calls (the UCI front end)
     def reset(self): lib.ora_search_reset(self.h)                                           # Agent::reset_search_state
     def reused_visits(self): return int(lib.ora_search_reused_visits(self.h))               # -1 = fresh root

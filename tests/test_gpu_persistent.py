@@ -210,6 +210,25 @@ def test_several_games_per_search_workgroup_equal_lockstep(hm, monkeypatch, per_
     assert cnt_p == cnt_l and rec_p == rec_l
 
 
+def test_single_launch_search_with_other_batch_sizes_equals_lockstep(hm):
+    """hm_sp_set_batch_sizes (Engine::getBatchSize() leaves per iteration) through k_rollout: same results as the lockstep kernels"""
+    net = _net()
+    G = 10
+    roots = O.random_positions(321, G * 9, 110)[::9][:G].copy()
+    sizes = np.array([4, 8, 2, 6, 4, 1, 8, 5, 3, 7], np.uint8)
+    eng = hm.SearchEngine(G, 421)
+    eng.set_batch_sizes(sizes)
+    eng.set_games(roots)
+    eng.begin_search(300, None, 0.3, 0.25)
+    eng.run(net)
+    want = eng.root_stats()
+    eng.set_games(roots)
+    eng.begin_search(300, None, 0.3, 0.25)
+    assert eng.search_persistent(net) > 0.0
+    _stats_equal(want, eng.root_stats(), G)
+    eng.close()
+
+
 def test_node_pool_of_the_headline_budget_fits_lds(hm):
     """BASELINE configs[2] / [3] (nodes 400: the self-play driver sizes the pool for 400 * 1.05 + 1 = 421 nodes): k_search must be able to keep the pool
     in LDS beside its static LDS.  A regression guard: one more LDS array in the kernel — or a helper the compiler stops inlining, whose

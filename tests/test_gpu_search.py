@@ -264,3 +264,39 @@ def test_persistent_search_with_many_transpositions_equals_lockstep(hm):
             assert np.array_equal(want["info"][g, :20], got["info"][g, :20]), (g, want["info"][g], got["info"][g])
         assert int(want["info"][:, 18].sum()) > 0
         eng.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 4, 7])
+def test_search_with_other_batch_sizes_matches_oracle(hm, batch):
+    """Engine::getBatchSize() leaves per iteration (searchthread.cc:258-273, 663) instead of the default 8: hm_sp_set_batch_sizes against
+    the oracle with the same cfg.batchSize — lockstep kernels under the hash evaluator; slots with different sizes in one engine."""
+    G = 12
+    roots = _roots(G, 4100 + batch)
+    sizes = np.full(G, batch, np.uint8)
+    sizes[1::3] = 8                                                          # mixed: every third slot keeps the default
+    eng = hm.SearchEngine(G, 500)
+    eng.set_games(roots)
+    eng.set_batch_sizes(sizes)
+    eng.begin_search(200, None, 0.0, 0.0)
+    eng.run(_hash_eval_gpu)
+    st = eng.root_stats()
+    searched = 0
+    for g in range(G):
+        b = O.Board()
+        b.from_compact(roots[g:g + 1])
+        s = O.Search(1, 1)
+        s.set_batch_size(int(sizes[g]))
+        if not s.run(b, int(roots["team"][g]), bool(roots["time_adv"][g]), 200):
+            assert st["info"][g][0] == 4
+            continue
+        searched += 1
+        e, oi, n = s.edges(), s.info(), st["counts"][g]
+        assert n == len(e["visits"]), (g, n, len(e["visits"]))
+        for k in ("move_a", "move_b", "visits", "prior", "q"):
+            assert np.array_equal(st[k][g, :n], e[k]), (g, k)
+        info = st["info"][g]
+        assert (info[1], info[2], info[3], info[4], info[5]) == (oi["nodes"], oi["eval_rows"], oi["same_batch"], oi["reservation"], oi["node_count"]), (g, info, oi)
+        assert 200 <= oi["nodes"] < 200 + 2 * int(sizes[g])                  # the budget is overshot by less than two batches of this size
+    assert searched >= 8
+    eng.set_batch_sizes(None)                                                # back to 8 everywhere
+    eng.close()

@@ -33,7 +33,10 @@ def stand_in_networks(planes, acting):
 
 @pytest.mark.parametrize("kw", [dict(games=6, nodes=48, max_macro_plies=30, seed=3, concurrent_games=4),
                                 dict(games=4, nodes=64, max_macro_plies=20, seed=11, concurrent_games=8,
-                                     contender_pw_coefficient=1.25, baseline_pw_coefficient=3.0, dirichlet_epsilon=0.25)])
+                                     contender_pw_coefficient=1.25, baseline_pw_coefficient=3.0, dirichlet_epsilon=0.25),
+                                # per-side Engine batch sizes (tournament.h:19-20): each network's searches collect that many leaves per iteration
+                                dict(games=4, nodes=48, max_macro_plies=20, seed=5, concurrent_games=4, contender_batch_size=4, baseline_batch_size=6)],
+                         ids=["6x48", "4x64-pw", "4x48-batch4v6"])
 def test_tournament_reports_match_oracle_bytes(hm, kw):
     t = hm.Tournament(hm.default_tournament_config(**kw), evaluator=stand_in_networks)
     res = t.run()

@@ -121,7 +121,7 @@ def test_argument_checks_carry_the_reference_texts():
         h = C.c_void_p()
         rc = hm.lib.hm_tournament_create(C.byref(hm.default_tournament_config(**kw)), None, C.byref(io), None, cb, None, C.byref(h))
         assert rc != 0 and hm.lib.hm_last_error().decode() == text, (kw, hm.lib.hm_last_error())
-    # what the GPU engine does not build (a movetime tournament over a callback evaluator, other batch sizes) is refused with its
+    # what the GPU engine does not build (a movetime tournament over a callback evaluator, batch sizes above 8) is refused with its
     # own text, not silently ignored
     for kw in (dict(nodes=0, move_time_ms=100), dict(contender_batch_size=16)):
         h = C.c_void_p()
