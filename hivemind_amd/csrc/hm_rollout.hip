@@ -640,6 +640,9 @@ const void* rollout_kernel(int ctiles, int k5, int* waves) {
         if (e && std::atoi(e) == 8) { *waves = 8; return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 8>); }
         return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 4>);
     }
+#ifdef HM_ROLLOUT_FEW
+    return nullptr;                                            // diagnostic builds: RISEv3-small only (one translation unit holds all three search roles)
+#else
     if (ctiles == 4) return reinterpret_cast<const void*>(k_rollout<MODE, 4, true, 4>);
     if (ctiles == 2) return reinterpret_cast<const void*>(k_rollout<MODE, 2, true, 4>);
     if (ctiles == 12) {
@@ -649,6 +652,7 @@ const void* rollout_kernel(int ctiles, int k5, int* waves) {
         return reinterpret_cast<const void*>(k_rollout<MODE, 12, true, 8>);
     }
     return nullptr;
+#endif
 }
 }  // namespace
 #define HM_ROLLOUT_ENTRY_(m) hm_rollout_kernel_mode##m

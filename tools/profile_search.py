@@ -8,9 +8,7 @@ import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "hivemind_amd", "csrc", "libhivemind_amd_prof.so")
 if "--build" in sys.argv:
-    src = [os.path.join(ROOT, "hivemind_amd", "csrc", f) for f in ("hm_kernels.hip", "hm_search.hip", "hm_selfplay.hip", "hm_net.hip", "hm_engine.hip", "hm_uci.hip")]
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing", "-fPIC", "-shared", "-DHM_SEARCH_PROF",
-                           "-I", os.path.join(ROOT, "include"), *src, "-o", PROF])
+    subprocess.check_call(["make", "-s", "-j6", "libhivemind_amd_prof.so"], cwd=os.path.join(ROOT, "hivemind_amd", "csrc"))   # -DHM_SEARCH_PROF -DHM_SINGLE_TU
     print("built", PROF)
     sys.exit(0)
 os.environ.setdefault("HIVEMIND_AMD_LIB", PROF)
