@@ -17,14 +17,15 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for d in a.dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.match(r"_ZN3hmn19rise_forward_narrowILi(\d+)ELb(\d)EE", row["Kernel_Name"].strip())
+            m = re.match(r"_ZN3hmn(19rise_forward_narrow|20rise_forward_narrow4)ILi(\d+)ELb(\d)EE", row["Kernel_Name"].strip())
             if not m:
                 continue
-            name = {"4": "small (RISEv3-small, 512 rows)", "12": "full (RISEv3.3, 512 rows)"}.get(m.group(1), "CTILES=" + m.group(1))
+            form = "4-wave form" if m.group(1).startswith("20") else "8-wave form"
+            name = {"4": "small (RISEv3-small, 512 rows)", "12": "full (RISEv3.3, 512 rows)"}.get(m.group(2), "CTILES=" + m.group(2)) + ", " + form
             c = acc[name][row["Counter_Name"]]
             c[0] += float(row["Counter_Value"]); c[1] += 1
 out = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python3 tools/bench_net_quick.py 512 (tools/profile_net_sq.sh: two passes, no trace "
-                  "flags); per-launch averages of the 8-wave fused forward", "kernels": {}}
+                  "flags; the second pair of passes with HM_NET_WAVES=4); per-launch averages of the fused forward, both forms", "kernels": {}}
 for name, cs in acc.items():
     k = {c: v[0] / v[1] for c, v in cs.items()}
     k["launches"] = max(v[1] for v in cs.values())
