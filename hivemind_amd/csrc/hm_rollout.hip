@@ -629,15 +629,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_rollout(Pools pl, Params prm,
 namespace {
 // -> the k_rollout instantiation for a trunk of `ctiles` * 32 channels and its waves per workgroup (nullptr: none)
 template <int MODE>
-const void* rollout_kernel(int ctiles, int k5, int* waves) {
+const void* rollout_kernel(int ctiles, int k5, int narrow8, int* waves) {
     using namespace hms;
     // (4, false) is the bench's RISEv3-small (no 5x5 block: the 5x5 depthwise code and its registers are left out); every other
     // narrow trunk runs the K5 = true instantiation of its width, which also handles 3x3 blocks.  The 384-channel trunk gets
     // eight-wave workgroups (HM_ROLLOUT_WAVES_WIDE=4 selects the four-wave kernel for measurements).
     *waves = 4;
     if (ctiles == 4 && !k5) {
-        const char* e = std::getenv("HM_ROLLOUT_WAVES_NARROW");                  // measurement switch: RISEv3-small on the eight-wave kernel
-        if (e && std::atoi(e) == 8) { *waves = 8; return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 8>); }
+        // narrow8: the caller asks for the eight-wave kernel (hm_sp_search: many games alive — the search is bound by the evaluator then)
+        if (narrow8) { *waves = 8; return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 8>); }
         return reinterpret_cast<const void*>(k_rollout<MODE, 4, false, 4>);
     }
 #ifdef HM_ROLLOUT_FEW
@@ -659,10 +659,10 @@ const void* rollout_kernel(int ctiles, int k5, int* waves) {
 #define HM_ROLLOUT_ENTRY(m) HM_ROLLOUT_ENTRY_(m)
 extern "C" {
 #ifdef HM_SINGLE_TU
-const void* hm_rollout_kernel_mode0(int ctiles, int k5, int* waves) { return rollout_kernel<0>(ctiles, k5, waves); }
-const void* hm_rollout_kernel_mode1(int ctiles, int k5, int* waves) { return rollout_kernel<1>(ctiles, k5, waves); }
-const void* hm_rollout_kernel_mode2(int ctiles, int k5, int* waves) { return rollout_kernel<2>(ctiles, k5, waves); }
+const void* hm_rollout_kernel_mode0(int ctiles, int k5, int narrow8, int* waves) { return rollout_kernel<0>(ctiles, k5, narrow8, waves); }
+const void* hm_rollout_kernel_mode1(int ctiles, int k5, int narrow8, int* waves) { return rollout_kernel<1>(ctiles, k5, narrow8, waves); }
+const void* hm_rollout_kernel_mode2(int ctiles, int k5, int narrow8, int* waves) { return rollout_kernel<2>(ctiles, k5, narrow8, waves); }
 #else
-const void* HM_ROLLOUT_ENTRY(HM_ROLLOUT_MODE)(int ctiles, int k5, int* waves) { return rollout_kernel<HM_ROLLOUT_MODE>(ctiles, k5, waves); }
+const void* HM_ROLLOUT_ENTRY(HM_ROLLOUT_MODE)(int ctiles, int k5, int narrow8, int* waves) { return rollout_kernel<HM_ROLLOUT_MODE>(ctiles, k5, narrow8, waves); }
 #endif
 }

@@ -1232,11 +1232,14 @@ int hm_sp_search_consumers(const hm_sp* sp) {
     return rollout_plan(sp, false, nullptr, nullptr, &consumers) ? consumers : 0;
 }
 
+#ifndef HM_ROLLOUT_WAVES8_MIN_ACT_DEFAULT
+#define HM_ROLLOUT_WAVES8_MIN_ACT_DEFAULT 1000000       // (off: see DESIGN.md 4b for the measurement)
+#endif
 // hm_rollout.hip, one entry per search role (0: node pool in LDS, 1: tree walked in place, 2: several games per search workgroup):
 // the k_rollout instantiation for a trunk of `ctiles` * 32 channels (k5: some block has a 5x5 depthwise), or nullptr
-const void* hm_rollout_kernel_mode0(int ctiles, int k5, int* waves);
-const void* hm_rollout_kernel_mode1(int ctiles, int k5, int* waves);
-const void* hm_rollout_kernel_mode2(int ctiles, int k5, int* waves);
+const void* hm_rollout_kernel_mode0(int ctiles, int k5, int narrow8, int* waves);
+const void* hm_rollout_kernel_mode1(int ctiles, int k5, int narrow8, int* waves);
+const void* hm_rollout_kernel_mode2(int ctiles, int k5, int narrow8, int* waves);
 
 // The whole node-budget search of every slot hm_sp_begin_search left in the searching state, with the native evaluator, as ONE
 // kernel launch (hm_rollout.hip: k_rollout — game workgroups and evaluator workgroups joined by the device-side queue of
@@ -1253,7 +1256,12 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
         return hm_fail(HM_ERR_INVALID, "too many game slots for a single-launch search on this device (use the lockstep calls)");
     const int mode = perWg > 1 ? 2 : (sp->searchLdsNodes ? 0 : 1);
     int waves = 4;                                             // waves per workgroup of this network's kernel (k_rollout: 4, or 8 for the 384-channel trunk)
-    const void* kern = mode == 0 ? hm_rollout_kernel_mode0(ni.C / 32, ni.k5, &waves) : mode == 1 ? hm_rollout_kernel_mode1(ni.C / 32, ni.k5, &waves) : hm_rollout_kernel_mode2(ni.C / 32, ni.k5, &waves);
+    // RISEv3-small: the eight-wave kernel (faster evaluator, slower search role) while at least this many games search — then the search is
+    // bound by the evaluator; the four-wave kernel (the reverse) otherwise.  Both give identical results.  HM_ROLLOUT_WAVES8_MIN_ACT overrides.
+    const int actNow = std::min(sp->lastBeginActive > 0 ? sp->lastBeginActive : sp->nGames, sp->nGames);
+    static const int min8 = [] { const char* e = std::getenv("HM_ROLLOUT_WAVES8_MIN_ACT"); return e ? std::atoi(e) : HM_ROLLOUT_WAVES8_MIN_ACT_DEFAULT; }();
+    const int narrow8 = actNow >= min8 ? 1 : 0;
+    const void* kern = mode == 0 ? hm_rollout_kernel_mode0(ni.C / 32, ni.k5, narrow8, &waves) : mode == 1 ? hm_rollout_kernel_mode1(ni.C / 32, ni.k5, narrow8, &waves) : hm_rollout_kernel_mode2(ni.C / 32, ni.k5, narrow8, &waves);
     if (!kern) return hm_fail(HM_ERR_INVALID, "no single-launch search kernel for this trunk width");
     // dynamic LDS: the larger of the two roles' layouts (they overlay each other); the evaluator's item word sits behind its own layout
     const size_t ldsSearch = search_lds_bytes(mode) + (mode == 0 ? (size_t)sp->prm.nodeCap * sizeof(Node) : 0);
@@ -1334,6 +1342,11 @@ int hm_sp_search(hm_sp* sp, const hm_net* net, const hm_eval_io* io, double* sea
     if (search_kernel_ms) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, sp->evT0, sp->evT1) == hipSuccess) *search_kernel_ms = ms; else { *search_kernel_ms = 0.0; (void)hipGetLastError(); }
+    }
+    if (std::getenv("HM_SEARCH_LOG")) {                            // measurement aid: one line per search
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp->evT0, sp->evT1) != hipSuccess) (void)hipGetLastError();
+        std::fprintf(stderr, "[hm_sp_search] act %d mode %d waves %d perWg %d consumers %d ms %.3f\n", actNow, mode, waves, perWg, consumers, ms);
     }
     const hmq::SrvQueue& hq = *hqp;                                // header only (the slots follow it on the device)
     sp->lastQueueError = hq.error;
