@@ -229,6 +229,28 @@ def test_single_launch_search_with_other_batch_sizes_equals_lockstep(hm):
     eng.close()
 
 
+@pytest.mark.parametrize("G", [300, 600])
+def test_many_game_slots_share_search_workgroups(hm, G):
+    """more game slots than a quarter of the CUs: rollout_plan lets the live games share search workgroups (search_role_mg, up to 8 per
+    workgroup) so that the launch stays resident at once; results equal the lockstep loop's.  With a mask that leaves few games alive
+    the same engine goes back to one game per workgroup."""
+    net = _net()
+    roots = O.random_positions(808, G * 3, 100)[::3][:G].copy()
+    eng = hm.SearchEngine(G, 100)
+    assert eng.search_consumers() > 0
+    for mask in (None, (np.arange(G) % 11 == 0).astype(np.uint8)):
+        eng.set_games(roots)
+        eng.begin_search(48, None, 0.0, 0.0, mask)
+        eng.run(net)
+        want = eng.root_stats()
+        eng.set_games(roots)
+        eng.begin_search(48, None, 0.0, 0.0, mask)
+        assert eng.search_persistent(net) > 0.0
+        assert getattr(eng, "stalls", 0) == 0
+        _stats_equal(want, eng.root_stats(), G)
+    eng.close()
+
+
 def test_node_pool_of_the_headline_budget_fits_lds(hm):
     """BASELINE configs[2] / [3] (nodes 400: the self-play driver sizes the pool for 400 * 1.05 + 1 = 421 nodes): k_search must be able to keep the pool
     in LDS beside its static LDS.  A regression guard: one more LDS array in the kernel — or a helper the compiler stops inlining, whose
